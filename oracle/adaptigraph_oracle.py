@@ -1,0 +1,347 @@
+"""CPU ORACLE for the AdaptiGraph GNN-dynamics rollout path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain numpy restatement of the reference algorithm.  It is the
+checker for the HIP path; it is never the thing shipped or measured.  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+The product package (adaptigraph_amd/) must never import this module.
+
+Parity pin: the reference holds NO golden vectors or tests for this path
+(SURVEY.md §4).  The oracle is pinned instead against outputs of the reference
+itself, generated in the build container by tests/golden/make_golden.py and
+committed as tests/golden/*.npz (tests/test_oracle_vs_golden.py: edge indices
+bit-exact, positions within 2e-6 per step).
+
+Each function cites the reference file:line it follows (paths relative to the
+reference repo root).
+
+Formulation notes
+  * The reference represents edges as dense one-hot matrices Rr/Rs (B,E,N) and
+    gathers/scatters with bmm.  A one-hot bmm is an exact gather, so the oracle
+    uses int32 (recv, send) index lists - identical values, no N*E memory.
+  * The scatter Rr^T.bmm(effect_rel) (model.py:324) is a sum whose order is
+    whatever the BLAS picks; the oracle sums in edge order with np.add.at.
+    This (and BLAS blocking inside the Linear layers) is why positions are
+    compared with a tolerance while edge indices are compared bit-for-bit.
+  * decode_action's cos/sin (plan_utils.py:11-20) are evaluated with torch CPU
+    ops, like the reference and like the product's host shim, so that the tool
+    trajectory bits are identical on both sides of every comparison.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+BIG = F32(1e10)
+
+WEIGHT_KEYS = [
+    "particle_encoder.model.0", "particle_encoder.model.2", "particle_encoder.model.4",
+    "relation_encoder.model.0", "relation_encoder.model.2", "relation_encoder.model.4",
+    "particle_propagator.linear", "relation_propagator.linear",
+    "non_rigid_predictor.linear_0", "non_rigid_predictor.linear_1", "non_rigid_predictor.linear_2",
+]
+
+
+class TopkTie(Exception):
+    """A tie at the k-th boundary inside the radius: the reference's answer is implementation-defined."""
+
+
+# --------------------------------------------------------------------------- edges
+def pairwise_dis(pos):
+    """graph.py:251-252  dis = sum((s_r - s_s)**2, -1), fp32, evaluated ((dx^2 + dy^2) + dz^2), no FMA."""
+    pos = np.ascontiguousarray(pos, dtype=F32)
+    d = pos[:, None, :] - pos[None, :, :]
+    sq = d * d
+    return (sq[..., 0] + sq[..., 1]) + sq[..., 2]
+
+
+def construct_edges_single(pos, thr, mask, tool_mask, topk, connect_tools_all, check_ties=False):
+    """One batch element of construct_edges_from_states_batch (graph.py:233-298).
+
+    pos (N,3) f32, thr python float or f32 scalar, mask/tool_mask (N,) bool.
+    Returns (recv, send) int32 arrays in the reference's row-major nonzero order
+    (sorted by recv, then send) == CSR by receiver.
+    """
+    N = pos.shape[0]
+    thr = F32(thr)
+    thr2 = F32(thr * thr)                                   # :248-250 fp32 square of an fp32 threshold
+    dis = pairwise_dis(pos)                                 # :251-252
+    mask = np.asarray(mask, bool)
+    tool = np.asarray(tool_mask, bool)
+    dis[~(mask[:, None] & mask[None, :])] = BIG             # :253-256
+    dis[tool[:, None] & tool[None, :]] = BIG                # :257-260
+    adj = (dis - thr2) < 0                                  # :267
+    k = min(N, int(topk))                                   # :270
+    if k < N:                                               # :271-274 (k == N keeps everything)
+        kth = np.partition(dis, k - 1, axis=1)[:, k - 1][:, None]
+        less = dis < kth
+        eq = dis == kth
+        need = k - less.sum(1, keepdims=True)
+        # ties: lowest sender index first == (distance, index) lexicographic order
+        sel = less | (eq & (np.cumsum(eq, axis=1) <= need))
+        if check_ties:
+            tied_in_radius = (eq.sum(1, keepdims=True) > need) & (kth < thr2)
+            if tied_in_radius.any():
+                raise TopkTie("tie at the k-th boundary inside the radius")
+        adj &= sel
+    if connect_tools_all:                                   # :276-286
+        pad_tool_1 = tool[:, None] & ~tool[None, :]         # :265 tool receiver, non-tool sender
+        flag = bool(adj[pad_tool_1].any())                  # :277 batch_mask
+        m1 = tool[:, None] & mask[None, :]                  # :262 obj_tool_mask_1
+        m2 = tool[None, :] & mask[:, None]                  # :263 obj_tool_mask_2
+        adj[m1] = False                                     # :283 / :285
+        adj[m2] = flag                                      # :284 / :286
+    recv, send = np.nonzero(adj)                            # :293 row-major
+    return recv.astype(np.int32), send.astype(np.int32)
+
+
+def construct_edges_batch(states, adj_thresh, mask, tool_mask, topk=10, connect_tools_all=False, check_ties=False):
+    """graph.py:233-298 for a batch.  adj_thresh: python float or (B,) array.  Returns list of (recv, send)."""
+    states = np.asarray(states, F32)
+    B = states.shape[0]
+    thr = np.full(B, F32(adj_thresh), F32) if np.isscalar(adj_thresh) else np.asarray(adj_thresh, F32)
+    return [construct_edges_single(states[b], thr[b], mask[b], tool_mask[b], topk, connect_tools_all, check_ties)
+            for b in range(B)]
+
+
+# --------------------------------------------------------------------------- model
+def _linear(x, W, b):
+    return x @ W.T + b
+
+
+def _relu(x):
+    return np.maximum(x, F32(0))
+
+
+def _encoder(x, W, pre):
+    """model.py:4-22 Encoder: Linear-ReLU x3 (ReLU after the last layer too)."""
+    for i in (0, 2, 4):
+        x = _relu(_linear(x, W[f"{pre}.model.{i}.weight"], W[f"{pre}.model.{i}.bias"]))
+    return x
+
+
+def model_forward_single(W, state, attrs, recv, send, group, action, phys, pstep, motion_clamp=100.0):
+    """DynamicsPredictor.forward (model.py:130-342) for ONE batch element, index-list form.
+
+    state (n_his,N,3); attrs (N,2); recv/send (E,) int; group (N,n_inst) = [p_instance ; 0] (model.py:264);
+    action (N,3); phys (N,) with zeros for the n_s trailing tool particles (model.py:206-207).
+    n_p (particles that get a prediction) = number of rows of p_instance = caller slices the output.
+    Returns (pred_pos_all (N,3), motion_all (N,3)) - caller keeps the first n_p rows (model.py:335-338).
+    """
+    state = np.asarray(state, F32)
+    n_his, N, _ = state.shape
+    res = state[1:] - state[:-1]                                            # :156
+    state_norm = np.concatenate([res, state[-1:]], 0)                       # :165
+    snt = np.ascontiguousarray(state_norm.transpose(1, 0, 2)).reshape(N, n_his * 3)   # :166
+    p_inputs = np.concatenate([attrs, phys[:, None], action], 1).astype(F32)  # :169,210,223 (state_dim=0)
+    attrs_r, attrs_s = attrs[recv], attrs[send]                             # :253-254
+    gdiff = np.abs(group[recv] - group[send]).sum(1, keepdims=True)         # :264-267
+    pos_diff = snt[recv] - snt[send]                                        # :277-279
+    rel_inputs = np.concatenate([attrs_r, attrs_s, gdiff, pos_diff], 1).astype(F32)  # :257,270,282
+    p_enc = _encoder(p_inputs, W, "particle_encoder")                       # :297
+    r_enc = _encoder(rel_inputs, W, "relation_encoder")                     # :303
+    eff = p_enc
+    Wrp, brp = W["relation_propagator.linear.weight"], W["relation_propagator.linear.bias"]
+    Wpp, bpp = W["particle_propagator.linear.weight"], W["particle_propagator.linear.bias"]
+    for _ in range(pstep):                                                  # :307
+        x = np.concatenate([r_enc, eff[recv], eff[send]], 1)                # :312-318
+        eff_rel = _relu(_linear(x, Wrp, brp))
+        agg = np.zeros((N, eff_rel.shape[1]), F32)                          # :324
+        np.add.at(agg, recv, eff_rel)
+        eff = _relu(_linear(np.concatenate([p_enc, agg], 1), Wpp, bpp) + eff)   # :328-330 (res added before ReLU)
+    h = _relu(_linear(eff, W["non_rigid_predictor.linear_0.weight"], W["non_rigid_predictor.linear_0.bias"]))
+    h = _relu(_linear(h, W["non_rigid_predictor.linear_1.weight"], W["non_rigid_predictor.linear_1.bias"]))
+    motion = _linear(h, W["non_rigid_predictor.linear_2.weight"], W["non_rigid_predictor.linear_2.bias"])  # :335
+    pred = state[-1] + np.clip(motion, -F32(motion_clamp), F32(motion_clamp))   # :338
+    return pred.astype(F32), motion.astype(F32)
+
+
+def model_forward(W, state, attrs, edges, p_instance, action, physics_param, pstep):
+    """Batched wrapper with the reference's argument meaning (model.py:130-131).
+
+    state (B,n_his,N,3), attrs (B,N,2), edges = list of (recv, send), p_instance (B,n_p,n_inst),
+    action (B,N,3), physics_param (B,1) or (B,n_p).  Returns pred_pos (B,n_p,3), pred_motion (B,n_p,3).
+    """
+    B, n_his, N, _ = state.shape
+    n_p, n_inst = p_instance.shape[1], p_instance.shape[2]
+    pos = np.zeros((B, n_p, 3), F32)
+    mot = np.zeros((B, n_p, 3), F32)
+    for b in range(B):
+        phys = np.zeros(N, F32)
+        pp = np.asarray(physics_param[b], F32).reshape(-1)
+        phys[:n_p] = pp[0] if pp.size == 1 else pp                          # :191-207
+        group = np.zeros((N, n_inst), F32)
+        group[:n_p] = p_instance[b]                                         # :264
+        p, m = model_forward_single(W, state[b], attrs[b], edges[b][0], edges[b][1], group, action[b], phys, pstep)
+        pos[b], mot[b] = p[:n_p], m[:n_p]
+    return pos, mot
+
+
+# --------------------------------------------------------------------------- rollout driver
+def decode_action(action, push_length):
+    """plan_utils.py:11-20.  torch CPU cos/sin so the bits equal the reference's."""
+    import torch
+    a = torch.as_tensor(np.asarray(action, F32))
+    x, z, th, ln = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    rep = ln.to(torch.int32)
+    x_end = x - push_length * torch.cos(th)
+    z_end = z - push_length * torch.sin(th)
+    dec = torch.stack([x, z, x_end, z_end], -1)
+    return dec.numpy(), rep.numpy()
+
+
+def tool_keypoints(decoded, theta, task):
+    """forward_dynamics.py:42-81 without the y row (y depends on the current particle cloud).
+
+    decoded (...,4) [x0,z0,x1,z1], theta (...,) -> eef_xz (...,M,2), eef_delta (...,M,3) fp32.
+    """
+    import torch
+    dec = torch.as_tensor(decoded)
+    th = torch.as_tensor(np.asarray(theta, F32))
+    pts = task["pusher_points"]
+    ratio = task["sim_real_ratio"]
+    lead = dec.shape[:-1]
+    M = len(pts)
+    if M not in (1, 5):
+        raise NotImplementedError("pusher not implemented")                 # :77-78
+    xz = torch.zeros(lead + (M, 2))
+    delta = torch.zeros(lead + (M, 3))
+    delta[..., 0] = (dec[..., 2] - dec[..., 0]).unsqueeze(-1)               # :48 / :56
+    delta[..., 2] = (dec[..., 3] - dec[..., 1]).unsqueeze(-1)               # :50 / :58
+    xz[..., 0, 0] = dec[..., 0]
+    xz[..., 0, 1] = dec[..., 1]
+    for k in range(1, M):                                                   # :65-75
+        c = float(pts[k][1]) * ratio
+        xz[..., k, 0] = dec[..., 0] + c * torch.sin(th)
+        xz[..., k, 1] = dec[..., 1] - c * torch.cos(th)
+    return xz.numpy(), delta.numpy()
+
+
+def _rollout_candidate(W, pstep, obj0, obj_mask, eef_xz, eef_delta, repeat, task, y_mode, phys_val, max_nR,
+                       trace=None):
+    """One candidate, one look-ahead step: forward_dynamics.py:83-197 (and :278-393 for the masked variant).
+
+    obj0 (N_o,3) start cloud (all n_his history frames equal it, :25/:38/:227); returns captured state or None.
+    """
+    N_o = obj0.shape[0]
+    M = eef_xz.shape[0]
+    N = N_o + M
+    n_his = task["n_his"]
+    grip = F32(0.01 * task["sim_real_ratio"]) if task["gripper_enable"] else None
+
+    def tool_y(cloud):
+        if y_mode == "min":
+            y = cloud[:, 1].min()                                            # :40 / :163
+        else:
+            y = (cloud[:, 1] * obj_mask).sum(dtype=F32) / F32(obj_mask.sum())  # :235 / :359
+        y = F32(y)
+        return F32(y + grip) if grip is not None else y                     # :80-81 / :167-168
+
+    eef = np.zeros((M, 3), F32)
+    eef[:, 0], eef[:, 2] = eef_xz[:, 0], eef_xz[:, 1]
+    eef[:, 1] = tool_y(obj0)
+    cur = np.concatenate([obj0, eef], 0).astype(F32)
+    hist = np.repeat(cur[None], n_his, 0)                                   # :83-85
+    action = np.zeros((N, 3), F32)
+    action[N_o:] = eef_delta                                                # :87-88
+    attrs = np.zeros((N, 2), F32)
+    attrs[:N_o, 0] = obj_mask.astype(F32)                                   # :92 / :287
+    attrs[N_o:, 1] = 1                                                      # :93
+    group = np.zeros((N, 1), F32)
+    group[:int(obj_mask.sum()), 0] = 1                                      # :100-105 / :294-300 (first-count rows)
+    mask = np.concatenate([obj_mask, np.ones(M, bool)])                     # :107-109 / :302-304
+    tool = np.concatenate([np.zeros(N_o, bool), np.ones(M, bool)])          # :111-112
+    phys = np.zeros(N, F32)
+    phys[:N_o] = phys_val                                                   # :151 + model.py:197
+    captured = None
+    for ai in range(1, int(repeat) + 1):                                    # :156 (live steps only)
+        recv, send = construct_edges_single(hist[-1], task["adj_thresh"], mask, tool, task["topk"],
+                                            task["connect_tools_all"])      # :125 / :171
+        if len(recv) > max_nR:
+            raise Exception("Exceeds max dims")                             # utils.py:63-65 via :127-128
+        pred, motion = model_forward_single(W, hist, attrs, recv, send, group, action, phys, pstep)
+        pred = pred[:N_o]
+        if trace is not None:
+            trace.append({"recv": recv, "send": send, "state_last": hist[-1].copy(), "pred_pos": pred.copy()})
+        if ai == repeat:
+            captured = pred.copy()                                          # :160-161
+        eef_cur = hist[-1, N_o:] + action[N_o:]                             # :164
+        eef_cur[:, 1] = tool_y(pred)                                        # :163,166-168
+        cur = np.concatenate([pred, eef_cur], 0).astype(F32)                # :170
+        hist = np.concatenate([hist[1:], cur[None]], 0)                     # :176
+    return captured
+
+
+def dynamics(W, pstep, state, action, task, physics_param=0.5, trace=None):
+    """forward_dynamics.py:12-205.  state (N_o,3); action (B,H,4).  Returns dict like the reference.
+
+    Candidates are independent, so each is stepped alone for exactly repeat[b,li] steps;
+    the reference steps everyone to the batch max and discards the surplus (:156-161) - same outputs.
+    `trace`, if a list, receives per-candidate lists of per-forward records.
+    """
+    state = np.asarray(state, F32)
+    action = np.asarray(action, F32)
+    B, H, _ = action.shape
+    N_o = state.shape[0]
+    dec, rep = decode_action(action, task["push_length"])                   # :23
+    xz, delta = tool_keypoints(dec, action[..., 2], task)
+    out = np.zeros((B, H, N_o, 3), F32)                                     # :32
+    ones = np.ones(N_o, bool)
+    for b in range(B):
+        tr = [] if trace is not None else None
+        obj = state
+        for li in range(H):                                                 # :34
+            if li > 0:
+                obj = out[b, li - 1]                                        # :37-38
+            cap = _rollout_candidate(W, pstep, obj, ones, xz[b, li], delta[b, li], rep[b, li], task, "min",
+                                     F32(physics_param), task["max_nR"], tr)
+            if cap is not None:
+                out[b, li] = cap                                            # repeat==0 leaves zeros (:32,:160)
+        if trace is not None:
+            trace.append(tr)
+    return {"state_seqs": out, "action_seqs": dec}
+
+
+def dynamics_masked(W, pstep, state_init, state_mask, action, task, physics_param=0.5, trace=None):
+    """forward_dynamics.py:209-399.  state_init (B,max_nobj,3), state_mask (B,max_nobj) bool, action (B,4)."""
+    state_init = np.asarray(state_init, F32)
+    state_mask = np.asarray(state_mask, bool)
+    action = np.asarray(action, F32)
+    B = state_init.shape[0]
+    dec, rep = decode_action(action[:, None], task["push_length"])          # :218-223
+    dec, rep = dec[:, 0], rep[:, 0]
+    xz, delta = tool_keypoints(dec, action[:, 2], task)
+    out = np.zeros_like(state_init)                                         # :233
+    for b in range(B):
+        tr = [] if trace is not None else None
+        cap = _rollout_candidate(W, pstep, state_init[b], state_mask[b], xz[b], delta[b], rep[b], task, "mean",
+                                 F32(physics_param), task["max_nR"], tr)
+        if cap is not None:
+            out[b] = cap
+        if trace is not None:
+            trace.append(tr)
+    return {"state_seqs": out, "action_seqs": dec}
+
+
+# --------------------------------------------------------------------------- helpers shared by tests / bench
+def weights_from_npz(npz):
+    return {k[3:]: np.asarray(npz[k], F32) for k in npz.files if k.startswith("w::")}
+
+
+def random_weights(seed, nf=150, in_dim=6, rel_dim=17):
+    """nn.Linear-style U(-1/sqrt(fan_in), 1/sqrt(fan_in)) init with a numpy RNG (synthetic benches)."""
+    rng = np.random.default_rng(seed)
+    shapes = {
+        "particle_encoder.model.0": (nf, in_dim), "particle_encoder.model.2": (nf, nf),
+        "particle_encoder.model.4": (nf, nf),
+        "relation_encoder.model.0": (nf, rel_dim), "relation_encoder.model.2": (nf, nf),
+        "relation_encoder.model.4": (nf, nf),
+        "particle_propagator.linear": (nf, 2 * nf), "relation_propagator.linear": (nf, 3 * nf),
+        "non_rigid_predictor.linear_0": (nf, nf), "non_rigid_predictor.linear_1": (nf, nf),
+        "non_rigid_predictor.linear_2": (3, nf),
+    }
+    W = {}
+    for k, (o, i) in shapes.items():
+        bound = 1.0 / np.sqrt(i)
+        W[k + ".weight"] = rng.uniform(-bound, bound, (o, i)).astype(F32)
+        W[k + ".bias"] = rng.uniform(-bound, bound, (o,)).astype(F32)
+    return W

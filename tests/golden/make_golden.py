@@ -1,0 +1,431 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference (jhyau/AdaptiGraph) hot path.
+
+Runs ONLY in the build container, where /root/reference exists.  The GPU box
+never sees the reference: it sees the small .npz fixtures this script writes
+into tests/golden/ (data only: inputs, weights, expected outputs).
+
+What is driven (reference file:line):
+  * construct_edges_from_states_batch   src/dynamics/dataset/graph.py:233-298
+  * DynamicsPredictor.forward           src/dynamics/gnn/model.py:130-342
+  * dynamics / dynamics_masked          src/planning/forward_dynamics.py:12-205 / 209-399
+  * pad_torch "Exceeds max dims"        src/dynamics/utils.py:49-69
+
+Import recipe = SURVEY.md Appendix A: the viz/FPS-only modules dgl, cv2, moviepy
+are absent from this image and never touched by the hot path, so inert empty
+module objects are registered for them before importing.
+
+Usage:  python tests/golden/make_golden.py            (rewrites every fixture)
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+import yaml
+
+REF = "/root/reference/src"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    for name in ["dgl", "dgl.geometry", "cv2", "moviepy", "moviepy.editor"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["dgl.geometry"].farthest_point_sampler = None
+    from dynamics.gnn.model import DynamicsPredictor
+    from dynamics.dataset.graph import construct_edges_from_states_batch
+    from planning.forward_dynamics import dynamics, dynamics_masked
+    return DynamicsPredictor, construct_edges_from_states_batch, dynamics, dynamics_masked
+
+
+def quiet(fn, *a, **k):
+    """The fork prints inside the hot loop (model.py:20,185,...); swallow it."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def load_cfg(material):
+    with open(f"{REF}/config/dynamics/{material}.yaml") as f:
+        dyn = yaml.safe_load(f)
+    with open(f"{REF}/config/planning/{material}.yaml") as f:
+        task = yaml.safe_load(f)["task_config"]
+    return dyn, task
+
+
+def make_model(DynamicsPredictor, dyn, seed):
+    torch.manual_seed(seed)
+    model = DynamicsPredictor(dyn["model_config"], dyn["material_config"], dyn["dataset_config"],
+                              torch.device("cpu")).eval()
+    return model
+
+
+def weights_npz(model):
+    return {"w::" + k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def make_ppm(task, material, phys=0.5):
+    return types.SimpleNamespace(
+        task_config=task, eef_num=task["eef_num"], material=material,
+        material_dims=task["material_dims"], material_indices=task["material_indices"],
+        physics_param={material: torch.tensor([phys], dtype=torch.float32)},
+        adj_thresh=task["adj_thresh"])
+
+
+def edges_from_R(Rr, Rs):
+    """dense one-hot (B,E,N) -> per-batch (recv, send) int32; zero rows = padding
+    (same convention the reference's viz uses, src/dynamics/rollout/graph.py:215-217)."""
+    out = []
+    for b in range(Rr.shape[0]):
+        valid = Rr[b].sum(-1) > 0
+        assert torch.equal(valid, Rs[b].sum(-1) > 0)
+        n = int(valid.sum())
+        assert bool(valid[:n].all())
+        out.append((Rr[b, :n].argmax(-1).to(torch.int32).numpy(),
+                    Rs[b, :n].argmax(-1).to(torch.int32).numpy()))
+    return out
+
+
+def pack_edges(prefix, per_batch, store):
+    cnt = np.array([len(r) for r, _ in per_batch], np.int32)
+    store[prefix + "n_edges"] = cnt
+    store[prefix + "recv"] = np.concatenate([r for r, _ in per_batch]).astype(np.int32)
+    store[prefix + "send"] = np.concatenate([s for _, s in per_batch]).astype(np.int32)
+
+
+def assert_no_topk_boundary_tie(states, mask, tool_mask, thr, topk):
+    """torch.topk tie-breaking is implementation-defined; fixtures must not depend on it."""
+    s = states.numpy().astype(np.float32)
+    B, N, _ = s.shape
+    thr2 = np.float32(thr) * np.float32(thr)
+    for b in range(B):
+        d = s[b][:, None, :] - s[b][None, :, :]
+        sq = d * d
+        dis = (sq[..., 0] + sq[..., 1]) + sq[..., 2]
+        m = mask[b].numpy()
+        t = tool_mask[b].numpy()
+        dis[~(m[:, None] & m[None, :])] = np.float32(1e10)
+        dis[t[:, None] & t[None, :]] = np.float32(1e10)
+        k = min(N, topk)
+        srt = np.sort(dis, axis=1)
+        if k < N:
+            kth, nxt = srt[:, k - 1], srt[:, k]
+            bad = (kth == nxt) & (kth < thr2)
+            assert not bad.any(), f"top-k boundary tie in batch {b}"
+
+
+class Recorder:
+    """Wraps model.forward to capture what every rollout step saw and produced."""
+
+    def __init__(self, model):
+        self.steps = []
+        self._orig = model.forward
+        model.forward = self._fwd
+
+    def _fwd(self, **graph):
+        out = self._orig(**graph)
+        self.steps.append({
+            "edges": edges_from_R(graph["Rr"], graph["Rs"]),
+            "state_last": graph["state"][:, -1].numpy().copy(),
+            "pred_pos": out[0].numpy().copy(),
+            "pred_motion": out[1].numpy().copy(),
+        })
+        return out
+
+    def dump(self, store):
+        store["n_steps"] = np.int32(len(self.steps))
+        for i, st in enumerate(self.steps):
+            pack_edges(f"step{i}::", st["edges"], store)
+            store[f"step{i}::state_last"] = st["state_last"]
+            store[f"step{i}::pred_pos"] = st["pred_pos"]
+            store[f"step{i}::pred_motion"] = st["pred_motion"]
+
+
+# ---------------------------------------------------------------- synthetic clouds
+def rope_cloud(n, rng):
+    t = np.linspace(0.0, 1.0, n)
+    p = np.stack([-2.0 + 3.0 * t, np.zeros(n), 0.5 * np.sin(6.0 * t)], 1)
+    return (p + rng.normal(0, 0.01, p.shape)).astype(np.float32)
+
+
+def grid_cloud(side, pitch, jitter, rng, center=(-2.0, 0.0, 1.0)):
+    g = (np.arange(side) - (side - 1) / 2.0) * pitch
+    xx, zz = np.meshgrid(g, g, indexing="ij")
+    p = np.stack([xx.ravel() + center[0], np.zeros(side * side) + center[1], zz.ravel() + center[2]], 1)
+    return (p + rng.normal(0, jitter, p.shape)).astype(np.float32)
+
+
+def actions_near(cloud, B, H, rng, len_lo, len_hi):
+    """(B,H,4) = [x, z, theta, len]; start points around the cloud so the pusher touches it."""
+    c = cloud.mean(0)
+    a = np.zeros((B, H, 4), np.float32)
+    a[..., 0] = c[0] + rng.uniform(-0.6, 0.6, (B, H))
+    a[..., 1] = c[2] + rng.uniform(-0.6, 0.6, (B, H))
+    a[..., 2] = rng.uniform(-3.14, 3.14, (B, H))
+    a[..., 3] = rng.uniform(len_lo, len_hi, (B, H))
+    return a
+
+
+def task_scalars(task):
+    keep = ["adj_thresh", "topk", "connect_tools_all", "sim_real_ratio", "push_length", "gripper_enable",
+            "max_n", "max_nR", "n_his", "eef_num", "material", "pusher_points", "material_dims",
+            "material_indices"]
+    return {k: task[k] for k in keep}
+
+
+def gen_dynamics_case(name, material, cloud, B, H, len_lo, len_hi, seed, refs, max_nR):
+    DynamicsPredictor, _, dynamics, _ = refs
+    rng = np.random.default_rng(seed)
+    dyn, task = load_cfg(material)
+    task = dict(task)
+    task["max_nR"] = max_nR
+    model = make_model(DynamicsPredictor, dyn, seed)
+    ppm = make_ppm(task, material)
+    state = torch.from_numpy(cloud)
+    action = torch.from_numpy(actions_near(cloud, B, H, rng, len_lo, len_hi))
+    rec = Recorder(model)
+    np.random.seed(seed)
+    out = quiet(dynamics, state, action, model, torch.device("cpu"), ppm)
+    # tie check on every graph the reference built (positions fed to the edge builder)
+    N = cloud.shape[0] + task["eef_num"]
+    mask = torch.ones((B, N), dtype=torch.bool)
+    tool = torch.zeros((B, N), dtype=torch.bool)
+    tool[:, cloud.shape[0]:] = True
+    for st in rec.steps:
+        assert_no_topk_boundary_tie(torch.from_numpy(st["state_last"]), mask, tool, task["adj_thresh"], task["topk"])
+    store = weights_npz(model)
+    store["state0"] = cloud
+    store["action"] = action.numpy()
+    store["state_seqs"] = out["state_seqs"].numpy()
+    store["action_seqs"] = out["action_seqs"].numpy()
+    store["pstep"] = np.int32(dyn["model_config"]["pstep"])
+    store["task_json"] = np.frombuffer(json.dumps(task_scalars(task)).encode(), dtype=np.uint8)
+    rec.dump(store)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: steps={len(rec.steps)} E/step={[int(sum(len(r) for r, _ in s['edges'])) for s in rec.steps][:4]}"
+          f" -> {os.path.getsize(path)/1e6:.2f} MB")
+
+
+def gen_masked_case(name, material, seed, refs):
+    DynamicsPredictor, _, _, dynamics_masked = refs
+    rng = np.random.default_rng(seed)
+    dyn, task = load_cfg(material)
+    task = dict(task)
+    task["max_nR"] = 4000
+    model = make_model(DynamicsPredictor, dyn, seed)
+    ppm = make_ppm(task, material)
+    counts = [120, 80, 101]
+    max_nobj = 120
+    B = len(counts)
+    state_init = np.zeros((B, max_nobj, 3), np.float32)
+    mask = np.zeros((B, max_nobj), bool)
+    for b, c in enumerate(counts):
+        state_init[b, :c] = rope_cloud(c, rng)
+        mask[b, :c] = True
+    action = actions_near(state_init[0, :80], B, 1, rng, 2.2, 4.8)[:, 0]
+    rec = Recorder(model)
+    np.random.seed(seed)
+    out = quiet(dynamics_masked, torch.from_numpy(state_init), torch.from_numpy(mask), torch.from_numpy(action),
+                model, torch.device("cpu"), ppm)
+    store = weights_npz(model)
+    store["state_init"] = state_init
+    store["state_mask"] = mask
+    store["action"] = action
+    store["state_seqs"] = out["state_seqs"].numpy()
+    store["action_seqs"] = out["action_seqs"].numpy()
+    store["pstep"] = np.int32(dyn["model_config"]["pstep"])
+    store["task_json"] = np.frombuffer(json.dumps(task_scalars(task)).encode(), dtype=np.uint8)
+    rec.dump(store)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: steps={len(rec.steps)} -> {os.path.getsize(path)/1e6:.2f} MB")
+
+
+def gen_overflow_case(name, refs):
+    """max_nR too small: the planner path lets pad_torch's Exception escape (forward_dynamics.py:127)."""
+    DynamicsPredictor, _, dynamics, _ = refs
+    rng = np.random.default_rng(7)
+    dyn, task = load_cfg("rope")
+    task = dict(task)
+    task["max_nR"] = 500
+    model = make_model(DynamicsPredictor, dyn, 7)
+    ppm = make_ppm(task, "rope")
+    cloud = rope_cloud(100, rng)
+    action = actions_near(cloud, 2, 1, rng, 2.2, 2.8)
+    msg = None
+    try:
+        quiet(dynamics, torch.from_numpy(cloud), torch.from_numpy(action), model, torch.device("cpu"), ppm)
+    except Exception as e:  # noqa: BLE001 - the reference raises a bare Exception
+        msg = str(e)
+    assert msg == "Exceeds max dims", msg
+    store = weights_npz(model)
+    store["state0"] = cloud
+    store["action"] = action
+    store["pstep"] = np.int32(dyn["model_config"]["pstep"])
+    store["task_json"] = np.frombuffer(json.dumps(task_scalars(task)).encode(), dtype=np.uint8)
+    store["expected_exception"] = np.frombuffer(msg.encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+    print(f"{name}: reference raised Exception({msg!r})")
+
+
+def gen_edges_cases(name, refs):
+    """Edge builder alone: ragged masks, several tools, both connect_tools_all modes, far tool (flag false)."""
+    _, construct, _, _ = refs
+    rng = np.random.default_rng(11)
+    store = {}
+    cases = []
+    ci = 0
+    for (N_o, M, topk, thr, cta, far_tool) in [
+        (150, 1, 10, 0.5, False, False),
+        (200, 5, 20, 0.4, False, False),
+        (200, 5, 20, 0.4, True, False),
+        (144, 1, 5, 0.75, True, False),
+        (144, 1, 5, 0.75, True, True),     # tool out of reach: connect_tools_all yields NO tool edges
+        (60, 2, 100, 0.45, False, False),  # topk > N
+        (64, 1, 3, 10.0, False, False),    # radius covers everything: pure top-k
+    ]:
+        B = 3
+        N = N_o + M
+        states = np.zeros((B, N, 3), np.float32)
+        mask = np.zeros((B, N), bool)
+        tool = np.zeros((B, N), bool)
+        tool[:, N_o:] = True
+        mask[:, N_o:] = True
+        for b in range(B):
+            cnt = [N_o, max(2, N_o * 2 // 3), max(2, N_o - 7)][b]
+            side = int(np.ceil(np.sqrt(cnt)))
+            cloud = grid_cloud(side, 0.12 if thr < 0.45 else 0.3 if thr > 0.7 else 0.1, 0.02, rng)[:cnt]
+            states[b, :cnt] = cloud
+            mask[b, :cnt] = True
+            c = cloud.mean(0)
+            for m in range(M):
+                off = 50.0 if far_tool else 0.0
+                states[b, N_o + m] = [c[0] + 0.05 * m + off + rng.normal(0, 0.01), 0.0,
+                                      c[2] + 0.04 * m + rng.normal(0, 0.01)]
+        ts, tm, tt = torch.from_numpy(states), torch.from_numpy(mask), torch.from_numpy(tool)
+        assert_no_topk_boundary_tie(ts, tm, tt, thr, topk)
+        Rr, Rs = construct(ts, thr, tm, tt, topk=topk, connect_tools_all=cta)
+        pre = f"case{ci}::"
+        store[pre + "states"] = states
+        store[pre + "mask"] = mask
+        store[pre + "tool_mask"] = tool
+        pack_edges(pre, edges_from_R(Rr, Rs), store)
+        cases.append({"N_o": N_o, "M": M, "topk": topk, "adj_thresh": thr, "connect_tools_all": cta})
+        ci += 1
+    # per-batch adj_thresh tensor variant (graph.py:248-250 accepts a (B,) tensor)
+    B, N_o, M = 3, 100, 1
+    N = N_o + M
+    states = np.zeros((B, N, 3), np.float32)
+    for b in range(B):
+        states[b, :N_o] = rope_cloud(N_o, rng)
+        states[b, N_o] = states[b, 40] + np.float32([0.03, 0.0, 0.02])
+    mask = np.ones((B, N), bool)
+    tool = np.zeros((B, N), bool)
+    tool[:, N_o:] = True
+    thr_t = torch.tensor([0.3, 0.5, 0.4], dtype=torch.float32)
+    Rr, Rs = construct(torch.from_numpy(states), thr_t, torch.from_numpy(mask), torch.from_numpy(tool),
+                       topk=8, connect_tools_all=False)
+    pre = f"case{ci}::"
+    store[pre + "states"], store[pre + "mask"], store[pre + "tool_mask"] = states, mask, tool
+    store[pre + "adj_thresh_vec"] = thr_t.numpy()
+    pack_edges(pre, edges_from_R(Rr, Rs), store)
+    cases.append({"N_o": N_o, "M": M, "topk": 8, "adj_thresh": None, "connect_tools_all": False})
+    store["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: {len(cases)} cases -> {os.path.getsize(path)/1e6:.2f} MB")
+
+
+def gen_forward_case(name, refs):
+    """One model(**graph) call with per-particle physics_param (B, n_p) (model.py:200-204) and dense Rr/Rs."""
+    DynamicsPredictor, construct, _, _ = refs
+    rng = np.random.default_rng(5)
+    dyn, task = load_cfg("granular")
+    model = make_model(DynamicsPredictor, dyn, 5)
+    B, N_o, M, n_his = 2, 150, 5, 4
+    N = N_o + M
+    base = grid_cloud(13, 0.12, 0.02, rng)[:N_o]
+    state = np.zeros((B, n_his, N, 3), np.float32)
+    for b in range(B):
+        for h in range(n_his):
+            state[b, h, :N_o] = base + rng.normal(0, 0.01, base.shape).astype(np.float32) * (h + 1)
+            state[b, h, N_o:] = base[70 + b] + np.float32([0.05, 0.0, 0.03]) * np.arange(M)[:, None] + 0.01 * h
+    attrs = np.zeros((B, N, 2), np.float32)
+    attrs[:, :N_o, 0] = 1
+    attrs[:, N_o:, 1] = 1
+    action = np.zeros((B, N, 3), np.float32)
+    action[:, N_o:] = rng.normal(0, 0.1, (B, 1, 3)).astype(np.float32)
+    p_instance = np.ones((B, N_o, 1), np.float32)
+    phys = rng.uniform(0.1, 0.9, (B, N_o)).astype(np.float32)
+    mask = np.ones((B, N), bool)
+    tool = np.zeros((B, N), bool)
+    tool[:, N_o:] = True
+    ts = torch.from_numpy(state)
+    assert_no_topk_boundary_tie(ts[:, -1], torch.from_numpy(mask), torch.from_numpy(tool), 0.4, 20)
+    Rr, Rs = construct(ts[:, -1], 0.4, torch.from_numpy(mask), torch.from_numpy(tool), topk=20, connect_tools_all=False)
+    graph = dict(state=ts, attrs=torch.from_numpy(attrs), Rr=Rr, Rs=Rs, p_instance=torch.from_numpy(p_instance),
+                 action=torch.from_numpy(action), granular_physics_param=torch.from_numpy(phys))
+    with torch.no_grad():
+        pred_pos, pred_motion = quiet(model, **graph)
+    store = weights_npz(model)
+    store.update(state=state, attrs=attrs, action=action, p_instance=p_instance, physics_param=phys,
+                 pred_pos=pred_pos.numpy(), pred_motion=pred_motion.numpy(), pstep=np.int32(3))
+    pack_edges("", edges_from_R(Rr, Rs), store)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: E={[len(r) for r, _ in edges_from_R(Rr, Rs)]} -> {os.path.getsize(path)/1e6:.2f} MB")
+
+
+def time_reference(refs):
+    """Reference dynamics() wall time in this container (8 threads) for DESIGN.md / BASELINE notes."""
+    DynamicsPredictor, _, dynamics, _ = refs
+    rows = []
+    for material, cloud_fn, B, H, ln in [
+        ("rope", lambda r: rope_cloud(300, r), 8, 2, 2.5),
+        ("cloth", lambda r: grid_cloud(45, 0.3, 0.02, r), 1, 1, 2.5),
+        ("cloth", lambda r: grid_cloud(45, 0.3, 0.02, r), 2, 1, 2.5),
+    ]:
+        rng = np.random.default_rng(0)
+        dyn, task = load_cfg(material)
+        task = dict(task)
+        task["max_nR"] = 30000
+        model = make_model(DynamicsPredictor, dyn, 0)
+        ppm = make_ppm(task, material)
+        cloud = cloud_fn(rng)
+        action = torch.from_numpy(actions_near(cloud, B, H, rng, ln, ln + 0.1))
+        t = []
+        for _ in range(3):
+            t0 = time.time()
+            quiet(dynamics, torch.from_numpy(cloud), action, model, torch.device("cpu"), ppm)
+            t.append(time.time() - t0)
+        steps = B * H * int(ln)
+        rows.append({"material": material, "N_o": int(cloud.shape[0]), "B": B, "H": H, "repeat": int(ln),
+                     "median_s": float(np.median(t)), "rollout_steps_per_s": steps / float(np.median(t)),
+                     "threads": torch.get_num_threads()})
+        print(rows[-1])
+    with open(os.path.join(OUT, "reference_timing.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+
+
+def main():
+    refs = import_reference()
+    rng = np.random.default_rng(0)
+    gen_edges_cases("edges_batch", refs)
+    gen_forward_case("forward_perparticle_phys", refs)
+    gen_dynamics_case("dyn_rope", "rope", rope_cloud(300, rng), B=4, H=3, len_lo=2.1, len_hi=3.9, seed=1, refs=refs, max_nR=4000)
+    gen_dynamics_case("dyn_granular", "granular", grid_cloud(20, 0.12, 0.02, rng), B=2, H=2, len_lo=2.1, len_hi=3.9, seed=2, refs=refs, max_nR=12000)
+    gen_dynamics_case("dyn_cloth", "cloth", grid_cloud(20, 0.3, 0.02, rng), B=2, H=2, len_lo=2.1, len_hi=3.9, seed=3, refs=refs, max_nR=4000)
+    gen_masked_case("dyn_masked_rope", "rope", 4, refs)
+    gen_overflow_case("dyn_overflow", refs)
+    if "--time" in sys.argv:
+        time_reference(refs)
+
+
+if __name__ == "__main__":
+    main()

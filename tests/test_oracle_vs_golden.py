@@ -1,0 +1,73 @@
+"""Pin the numpy oracle against outputs of the REAL reference (tests/golden/*.npz, made by
+tests/golden/make_golden.py in the build container).  CPU only.
+
+Bars: edge indices bit-exact; positions within POS_TOL per forward and over the free-running rollout.
+"""
+import numpy as np
+import pytest
+
+from oracle import adaptigraph_oracle as O
+from helpers import load_golden, task_of, split_edges, golden_step_index
+
+POS_TOL = 5e-6   # fp32; BLAS summation order differs between torch-MKL and numpy (oracle docstring)
+
+
+def test_edges_batch_bit_exact():
+    g = load_golden("edges_batch")
+    import json
+    cases = json.loads(bytes(g["cases_json"]).decode())
+    for ci, c in enumerate(cases):
+        pre = f"case{ci}::"
+        thr = c["adj_thresh"] if c["adj_thresh"] is not None else g[pre + "adj_thresh_vec"]
+        got = O.construct_edges_batch(g[pre + "states"], thr, g[pre + "mask"], g[pre + "tool_mask"],
+                                      c["topk"], c["connect_tools_all"], check_ties=True)
+        want = split_edges(g, pre)
+        for b, ((r, s), (wr, ws)) in enumerate(zip(got, want)):
+            assert np.array_equal(r, wr) and np.array_equal(s, ws), (ci, b)
+
+
+def test_forward_per_particle_physics():
+    g = load_golden("forward_perparticle_phys")
+    W = O.weights_from_npz(g)
+    edges = split_edges(g, "")
+    pos, mot = O.model_forward(W, g["state"], g["attrs"], edges, g["p_instance"], g["action"],
+                               g["physics_param"], int(g["pstep"]))
+    assert np.abs(pos - g["pred_pos"]).max() < POS_TOL
+    assert np.abs(mot - g["pred_motion"]).max() < POS_TOL
+
+
+@pytest.mark.parametrize("name", ["dyn_rope", "dyn_granular", "dyn_cloth"])
+def test_dynamics_free_running(name):
+    g = load_golden(name)
+    W, task = O.weights_from_npz(g), task_of(g)
+    trace = []
+    out = O.dynamics(W, int(g["pstep"]), g["state0"], g["action"], task, trace=trace)
+    assert np.array_equal(out["action_seqs"], g["action_seqs"])
+    _, rep = O.decode_action(g["action"], task["push_length"])
+    base = golden_step_index(rep)
+    for b, tr in enumerate(trace):
+        k = 0
+        for li in range(rep.shape[1]):
+            for ai in range(rep[b, li]):
+                gi = base[li] + ai
+                wr, ws = split_edges(g, f"step{gi}::")[b]
+                assert np.array_equal(tr[k]["recv"], wr) and np.array_equal(tr[k]["send"], ws), (b, li, ai)
+                assert np.abs(tr[k]["pred_pos"] - g[f"step{gi}::pred_pos"][b]).max() < POS_TOL
+                k += 1
+    assert np.abs(out["state_seqs"] - g["state_seqs"]).max() < POS_TOL
+
+
+def test_dynamics_masked():
+    g = load_golden("dyn_masked_rope")
+    W, task = O.weights_from_npz(g), task_of(g)
+    out = O.dynamics_masked(W, int(g["pstep"]), g["state_init"], g["state_mask"], g["action"], task)
+    assert np.array_equal(out["action_seqs"], g["action_seqs"])
+    assert np.abs(out["state_seqs"] - g["state_seqs"]).max() < POS_TOL
+
+
+def test_overflow_raises_like_reference():
+    g = load_golden("dyn_overflow")
+    W, task = O.weights_from_npz(g), task_of(g)
+    with pytest.raises(Exception, match="Exceeds max dims"):
+        O.dynamics(W, int(g["pstep"]), g["state0"], g["action"], task)
+    assert bytes(g["expected_exception"]).decode() == "Exceeds max dims"
