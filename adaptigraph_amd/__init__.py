@@ -1,0 +1,15 @@
+"""adaptigraph_amd - MI355X-native GNN-dynamics rollout engine with AdaptiGraph's call signatures.
+
+    from adaptigraph_amd import DynamicsPredictor, dynamics, dynamics_masked
+    from adaptigraph_amd import construct_edges_from_states_batch, pad_torch, truncate_graph, decode_action
+
+Hand-written HIP kernels (adaptigraph_amd/csrc) behind a C-ABI (include/adaptigraph_amd.h).  No CPU fallback.
+"""
+from .context import Engine, default_engine
+from .forward_dynamics import dynamics, dynamics_masked
+from .graph import EdgeList, construct_edges_from_states_batch, construct_edges_index, pad_torch, truncate_graph
+from .model import DynamicsPredictor
+from .plan_utils import decode_action
+
+__all__ = ["Engine", "default_engine", "dynamics", "dynamics_masked", "EdgeList", "construct_edges_from_states_batch",
+           "construct_edges_index", "pad_torch", "truncate_graph", "DynamicsPredictor", "decode_action"]

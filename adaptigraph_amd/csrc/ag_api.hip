@@ -1,0 +1,495 @@
+// C-ABI of the MI355X-native GNN-dynamics rollout engine (see include/adaptigraph_amd.h).
+// Host orchestration only: context, workspace, weight repacking, launch sequences.  No CPU compute fallback.
+#include "../../include/adaptigraph_amd.h"
+#include "ag_common.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace ag {
+size_t edge_build_max_particles();
+}
+using namespace ag;
+
+namespace {
+
+const char* kFamilyNames[FAM_COUNT] = {"edge_count", "edge_emit", "prep", "node_enc", "edge_enc",
+                                       "mp", "node_prop", "node_final", "roll_init", "roll_update"};
+
+struct Slab {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    template <typename T> T* take(size_t n) {
+        used = (used + 255) & ~size_t(255);
+        T* p = reinterpret_cast<T*>(base + used);
+        used += n * sizeof(T);
+        return p;
+    }
+};
+
+struct ProfEvent { int fam; hipEvent_t e0, e1; };
+
+}  // namespace
+
+struct ag_ctx {
+    int device = 0;
+    ag_dims dims{};
+    std::string err;
+    float* d_w = nullptr;
+    bool have_w = false;
+    Slab slab;
+    int chunk = 0;
+    int* d_repeat = nullptr; size_t repeat_cap = 0;
+    std::vector<int> h_repeat;   // ctx-owned copy so the caller's array may die right after the call
+    int* d_overflow = nullptr;
+    // profiling
+    unsigned prof_mask = 0;
+    std::vector<ProfEvent> prof_live;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[FAM_COUNT] = {0};
+    long long prof_n[FAM_COUNT] = {0};
+    hipStream_t prof_stream = nullptr;
+};
+
+namespace {
+
+int fail(ag_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+#define HIPCHK(c, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) return fail(c, AG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+void prof_mark(void* vc, int fam, int phase) {
+    ag_ctx* c = static_cast<ag_ctx*>(vc);
+    if (!(c->prof_mask & (1u << fam))) return;
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    if (phase == 0) {
+        ProfEvent p{fam, get(), get()};
+        (void)hipEventRecord(p.e0, c->prof_stream);
+        c->prof_live.push_back(p);
+    } else {
+        for (auto it = c->prof_live.rbegin(); it != c->prof_live.rend(); ++it)
+            if (it->fam == fam) { (void)hipEventRecord(it->e1, c->prof_stream); break; }
+    }
+}
+struct Scoped {
+    ag_ctx* c; int fam;
+    Scoped(ag_ctx* c_, int f) : c(c_), fam(f) { prof_mark(c, fam, 0); }
+    ~Scoped() { prof_mark(c, fam, 1); }
+};
+
+// ---------------------------------------------------------------------------------------------- weight packing
+// MFMA A-operand image of a layer: [chunk q][m-block][lane][4 steps]; lane l supplies out-feature 32*mb + (l&31)
+// for input slot k(s, l>>5).  See ag_mlp.hip header.
+int slot_of(int s, int h) {
+    const int t = s < 64 ? s / 16 : 4, r = s < 64 ? s % 16 : s - 64;
+    return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+void pack_layer(float* dst, const float* W, int ld, int col0, int out_dim, int in_dim, const float* bias, int MB) {
+    for (int q = 0; q < KCH; ++q)
+        for (int mb = 0; mb < MB; ++mb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int k = slot_of(4 * q + e, lane >> 5), m = 32 * mb + (lane & 31);
+                    float v = 0.f;
+                    if (m < out_dim) {
+                        if (k < in_dim) v = W[(size_t)m * ld + col0 + k];
+                        else if (k == ONE_F && bias) v = bias[m];
+                    }
+                    dst[((size_t)(q * MB + mb) * 64 + lane) * 4 + e] = v;
+                }
+}
+void pack_first(float* dst, const float* W, int in_dim, const float* bias, int nch) {
+    for (int q = 0; q < nch; ++q)
+        for (int mb = 0; mb < 5; ++mb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 2 * (4 * q + e) + (lane >> 5), m = 32 * mb + (lane & 31);
+                    float v = 0.f;
+                    if (m < NF) {
+                        if (k < in_dim) v = W[(size_t)m * in_dim + k];
+                        else if (k == in_dim) v = bias[m];
+                    }
+                    dst[((size_t)(q * 5 + mb) * 64 + lane) * 4 + e] = v;
+                }
+}
+
+// ---------------------------------------------------------------------------------------------- workspace
+struct Work {
+    GraphBufs g{};
+    RollBufs r{};
+    unsigned long long* tstar; int* deg; int* slice_tot; int* cta_flag;
+    int* recv; int* send; int* row_ptr; int* n_edges;
+};
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+int ensure_slab(ag_ctx* c, size_t bytes) {
+    if (c->slab.cap >= bytes) { c->slab.used = 0; return AG_OK; }
+    if (c->slab.base) HIPCHK(c, hipFree(c->slab.base));
+    c->slab.base = nullptr; c->slab.cap = 0;
+    const size_t want = round_up(bytes + (bytes >> 3), 1 << 20);
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->slab.base), want));
+    c->slab.cap = want; c->slab.used = 0;
+    return AG_OK;
+}
+
+// carve a workspace for Bc candidates.  own_edges: allocate edge index arrays + builder scratch; roll: rollout state
+int make_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices, bool own_edges,
+              bool roll, bool own_group, int N_o) {
+    const size_t rows = (size_t)Bc * N;
+    size_t bytes = 0;
+    bytes += 16 * 256;
+    bytes += rows * (NODE_IN + F12 + (own_group ? n_inst : 0)) * 4 + 5 * rows * NFP * 4 + (size_t)Bc * c_cap * NFP * 4;
+    if (own_edges) bytes += rows * 12 + (size_t)Bc * (slices + 2) * 4 + 2 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
+    if (roll) bytes += (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows;
+    bytes += 64 * 256;
+    int rc = ensure_slab(c, bytes);
+    if (rc) return rc;
+    Slab& s = c->slab;
+    w.g.node_in = s.take<float>(rows * NODE_IN);
+    w.g.feat12 = s.take<float>(rows * F12);
+    w.g.group = own_group ? s.take<float>(rows * n_inst) : nullptr;
+    w.g.eff = s.take<float>(rows * NFP);
+    w.g.P = s.take<float>(rows * NFP);
+    w.g.U = s.take<float>(rows * NFP);
+    w.g.V = s.take<float>(rows * NFP);
+    w.g.agg = s.take<float>(rows * NFP);
+    w.g.C = s.take<float>((size_t)Bc * c_cap * NFP);
+    w.g.B = Bc; w.g.N = N; w.g.n_inst = n_inst; w.g.edge_cap = edge_cap; w.g.c_cap = c_cap; w.g.n_p = N_o;
+    if (own_edges) {
+        w.tstar = s.take<unsigned long long>(rows);
+        w.deg = s.take<int>(rows);
+        w.slice_tot = s.take<int>((size_t)Bc * slices);
+        w.cta_flag = s.take<int>(Bc);
+        w.recv = s.take<int>((size_t)Bc * edge_cap);
+        w.send = s.take<int>((size_t)Bc * edge_cap);
+        w.row_ptr = s.take<int>((size_t)Bc * (N + 1));
+        w.n_edges = s.take<int>(Bc);
+        w.g.recv = w.recv; w.g.send = w.send; w.g.row_ptr = w.row_ptr; w.g.n_edges = w.n_edges;
+    }
+    if (roll) {
+        w.r.hist = s.take<float>((size_t)Bc * N_HIS * N * 3);
+        w.r.pred = s.take<float>((size_t)Bc * N_o * 3);
+        w.r.motion = s.take<float>((size_t)Bc * N_o * 3);
+        w.r.mask = s.take<uint8_t>(rows);
+        w.r.tool = s.take<uint8_t>(rows);
+    }
+    if (s.used > s.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
+    return AG_OK;
+}
+
+int pick_slices(int B, int N) {
+    int s = (512 + B - 1) / B;
+    s = std::min(s, std::max(1, N / 64));
+    return std::max(1, std::min(s, 64));
+}
+
+int auto_chunk(const ag_ctx* c, int B, int N) {
+    if (c->chunk > 0) return std::min(c->chunk, B);
+    if (const char* e = getenv("AG_CHUNK")) { int v = atoi(e); if (v > 0) return std::min(v, B); }
+    const long target_rows = 131072;   // >= 2 full waves of 256-row workgroups on 256 CUs for the node chains
+    long bc = (target_rows + N - 1) / N;
+    return (int)std::max(1L, std::min<long>(bc, B));
+}
+
+// one model forward on a prepared workspace (node_in, feat12, group, edges all set)
+int run_model(ag_ctx* c, const GraphBufs& g, float* pred_pos, float* pred_motion, hipStream_t st) {
+    { Scoped p(c, FAM_NODE_ENC); HIPCHK(c, launch_node_enc(c->d_w, g, st)); }
+    { Scoped p(c, FAM_EDGE_ENC); HIPCHK(c, launch_edge_enc(c->d_w, g, st)); }
+    for (int ps = 0; ps < c->dims.pstep; ++ps) {
+        { Scoped p(c, FAM_MP); HIPCHK(c, launch_mp(g, st)); }
+        if (ps + 1 < c->dims.pstep) { Scoped p(c, FAM_NODE_PROP); HIPCHK(c, launch_node_prop(c->d_w, g, st)); }
+        else { Scoped p(c, FAM_NODE_FINAL); HIPCHK(c, launch_node_final(c->d_w, g, c->dims.motion_clamp, pred_pos, pred_motion, st)); }
+    }
+    return AG_OK;
+}
+
+int check_topk(ag_ctx* c, int N, int topk) {
+    if (N < 1 || topk < 1) return fail(c, AG_ERR_INVALID, "N and topk must be >= 1");
+    if ((size_t)N > edge_build_max_particles()) return fail(c, AG_ERR_UNSUPPORTED, "N=%d exceeds the LDS-resident edge builder limit %zu", N, edge_build_max_particles());
+    if (topk < N && topk > 128) return fail(c, AG_ERR_UNSUPPORTED, "topk=%d: 128 < topk < N is not implemented", topk);
+    return AG_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ C-ABI
+extern "C" {
+
+uint32_t ag_abi_version(void) { return AG_ABI_VERSION; }
+
+const char* ag_last_error(const ag_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int ag_ctx_create(int32_t device_id, const ag_dims* dims, ag_ctx** out) {
+    if (!dims || !out) return AG_ERR_INVALID;
+    *out = nullptr;
+    ag_ctx* c = new ag_ctx();
+    c->device = device_id; c->dims = *dims;
+    *out = c;   // returned even on failure so the caller can read ag_last_error, then destroy
+    if (dims->nf != NF || dims->n_his != N_HIS || dims->in_dim != IN_DIM || dims->rel_dim != REL_DIM)
+        return fail(c, AG_ERR_UNSUPPORTED, "kernels are built for nf=150, n_his=4, in_dim=6, rel_dim=17 (got %d,%d,%d,%d)",
+                    dims->nf, dims->n_his, dims->in_dim, dims->rel_dim);
+    if (dims->pstep < 1) return fail(c, AG_ERR_INVALID, "pstep must be >= 1");
+    HIPCHK(c, hipSetDevice(device_id));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_w), (size_t)WeightLayout::TOTAL * 4));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_overflow), 256));
+    return AG_OK;
+}
+
+int ag_ctx_destroy(ag_ctx* c) {
+    if (!c) return AG_OK;
+    (void)hipSetDevice(c->device);
+    for (auto& p : c->prof_live) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    for (auto e : c->prof_pool) (void)hipEventDestroy(e);
+    if (c->d_w) (void)hipFree(c->d_w);
+    if (c->d_overflow) (void)hipFree(c->d_overflow);
+    if (c->d_repeat) (void)hipFree(c->d_repeat);
+    if (c->slab.base) (void)hipFree(c->slab.base);
+    delete c;
+    return AG_OK;
+}
+
+int ag_ctx_set_chunk(ag_ctx* c, int32_t n) {
+    if (!c || n < 0) return AG_ERR_INVALID;
+    c->chunk = n;
+    return AG_OK;
+}
+
+int ag_ctx_load_weights(ag_ctx* c, const float* const* t, int32_t n) {
+    if (!c) return AG_ERR_INVALID;
+    if (!t || n != AG_NUM_WEIGHT_TENSORS) return fail(c, AG_ERR_INVALID, "expected %d weight tensors", AG_NUM_WEIGHT_TENSORS);
+    for (int i = 0; i < n; ++i) if (!t[i]) return fail(c, AG_ERR_INVALID, "weight tensor %d is null", i);
+    using WL = WeightLayout;
+    std::vector<float> blob((size_t)WL::TOTAL, 0.f);
+    float* b = blob.data();
+    // particle encoder 0..5, relation encoder 6..11
+    pack_first(b + WL::N_L1, t[0], IN_DIM, t[1], NODE_L1_CHUNKS);
+    pack_layer(b + WL::N_L2, t[2], NF, 0, NF, NF, t[3], 5);
+    pack_layer(b + WL::N_L3, t[4], NF, 0, NF, NF, t[5], 5);
+    pack_first(b + WL::E_L1, t[6], REL_DIM, t[7], EDGE_L1_CHUNKS);
+    pack_layer(b + WL::E_L2, t[8], NF, 0, NF, NF, t[9], 5);
+    pack_layer(b + WL::E_L3, t[10], NF, 0, NF, NF, t[11], 5);
+    // particle propagator W_pp = [Wa | Wb] (150 x 300), bias with Wa
+    pack_layer(b + WL::N_WA, t[12], 2 * NF, 0, NF, NF, t[13], 5);
+    pack_layer(b + WL::P_WB, t[12], 2 * NF, NF, NF, NF, nullptr, 5);
+    // relation propagator W_rp = [W1 | W2 | W3] (150 x 450), bias with W1
+    pack_layer(b + WL::E_W1, t[14], 3 * NF, 0, NF, NF, t[15], 5);
+    pack_layer(b + WL::N_W2, t[14], 3 * NF, NF, NF, NF, nullptr, 5);
+    pack_layer(b + WL::N_W3, t[14], 3 * NF, 2 * NF, NF, NF, nullptr, 5);
+    // predictor
+    pack_layer(b + WL::P_P0, t[16], NF, 0, NF, NF, t[17], 5);
+    pack_layer(b + WL::P_P1, t[18], NF, 0, NF, NF, t[19], 5);
+    pack_layer(b + WL::P_P2, t[20], NF, 0, 3, NF, t[21], 1);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(c->d_w, b, blob.size() * 4, hipMemcpyHostToDevice));
+    c->have_w = true;
+    return AG_OK;
+}
+
+int ag_build_edges(ag_ctx* c, void* stream, const float* d_pos, const uint8_t* d_mask, const uint8_t* d_tool,
+                   int32_t B, int32_t N, float thr, const float* d_thr_vec, int32_t topk, int32_t cta, int32_t edge_cap,
+                   int32_t* d_recv, int32_t* d_send, int32_t* d_row_ptr, int32_t* d_n_edges) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_pos || !d_mask || !d_tool || !d_recv || !d_send || !d_row_ptr || !d_n_edges || B < 1 || edge_cap < 1)
+        return fail(c, AG_ERR_INVALID, "ag_build_edges: null pointer or empty batch");
+    int rc = check_topk(c, N, topk);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int slices = pick_slices(B, N);
+    const size_t rows = (size_t)B * N;
+    rc = ensure_slab(c, rows * 12 + (size_t)B * (slices + 1) * 4 + 4096);
+    if (rc) return rc;
+    EdgeArgs a{};
+    a.pos = d_pos; a.pos_bstride = (long)N * 3; a.mask = d_mask; a.tool = d_tool; a.thr_vec = d_thr_vec; a.thr = thr;
+    a.B = B; a.N = N; a.topk = topk; a.cta = cta ? 1 : 0; a.edge_cap = edge_cap; a.slices = slices;
+    a.tstar = c->slab.take<unsigned long long>(rows);
+    a.deg = c->slab.take<int>(rows);
+    a.slice_tot = c->slab.take<int>((size_t)B * slices);
+    a.cta_flag = c->slab.take<int>(B);
+    a.recv = d_recv; a.send = d_send; a.row_ptr = d_row_ptr; a.n_edges = d_n_edges; a.overflow = nullptr;
+    a.max_nR = edge_cap; a.zero_on_overflow = 0;
+    c->prof_stream = static_cast<hipStream_t>(stream);
+    HIPCHK(c, launch_edge_build(a, static_cast<hipStream_t>(stream), prof_mark, c));
+    return AG_OK;
+}
+
+int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_attrs, const float* d_action,
+               const float* d_phys, const float* d_group, int32_t n_inst, const int32_t* d_recv, const int32_t* d_send,
+               const int32_t* d_row_ptr, const int32_t* d_n_edges, int32_t edge_cap, int32_t B, int32_t N, int32_t n_p,
+               float* d_pred_pos, float* d_pred_motion) {
+    if (!c) return AG_ERR_INVALID;
+    if (!c->have_w) return fail(c, AG_ERR_NO_WEIGHTS, "ag_forward before ag_ctx_load_weights");
+    if (!d_state || !d_attrs || !d_action || !d_phys || !d_group || !d_recv || !d_send || !d_row_ptr || !d_n_edges ||
+        !d_pred_pos || !d_pred_motion)
+        return fail(c, AG_ERR_INVALID, "ag_forward: null pointer");
+    if (B < 1 || N < 1 || n_p < 1 || n_p > N || n_inst < 1 || edge_cap < 1)
+        return fail(c, AG_ERR_INVALID, "ag_forward: bad sizes B=%d N=%d n_p=%d n_inst=%d edge_cap=%d", B, N, n_p, n_inst, edge_cap);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    c->prof_stream = st;
+    const int Bc = auto_chunk(c, B, N);
+    const int c_cap = (int)round_up(edge_cap, 256);
+    Work w{};
+    int rc = make_work(c, w, Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p);
+    if (rc) return rc;
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+        const int nb = std::min(Bc, B - b0);
+        GraphBufs g = w.g;
+        g.B = nb; g.n_p = n_p;
+        g.group = const_cast<float*>(d_group) + (size_t)b0 * N * n_inst;
+        g.recv = d_recv + (size_t)b0 * edge_cap; g.send = d_send + (size_t)b0 * edge_cap;
+        g.row_ptr = d_row_ptr + (size_t)b0 * (N + 1); g.n_edges = d_n_edges + b0;
+        { Scoped p(c, FAM_PREP);
+          HIPCHK(c, launch_prep(d_state + (size_t)b0 * N_HIS * N * 3, d_attrs + (size_t)b0 * N * 2,
+                                d_action + (size_t)b0 * N * 3, d_phys + (size_t)b0 * N, g, st)); }
+        rc = run_model(c, g, d_pred_pos + (size_t)b0 * n_p * 3, d_pred_motion + (size_t)b0 * n_p * 3, st);
+        if (rc) return rc;
+    }
+    return AG_OK;
+}
+
+int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0,
+                     const uint8_t* d_obj_mask, const float* d_eef_xz, const float* d_eef_delta,
+                     const int32_t* h_repeat, const float* d_phys_vec, float* d_state_seqs, int32_t* d_overflow_flag) {
+    if (!c) return AG_ERR_INVALID;
+    if (!c->have_w) return fail(c, AG_ERR_NO_WEIGHTS, "ag_rollout before ag_ctx_load_weights");
+    if (!p || !d_state0 || !d_eef_xz || !d_eef_delta || !h_repeat || !d_state_seqs || !d_overflow_flag)
+        return fail(c, AG_ERR_INVALID, "ag_rollout: null pointer");
+    if (p->B < 1 || p->H < 1 || p->N_o < 1 || p->M < 1 || p->max_nR < 1)
+        return fail(c, AG_ERR_INVALID, "ag_rollout: bad sizes B=%d H=%d N_o=%d M=%d max_nR=%d", p->B, p->H, p->N_o, p->M, p->max_nR);
+    if (p->y_mode != 0 && p->y_mode != 1) return fail(c, AG_ERR_INVALID, "y_mode must be 0 or 1");
+    if (p->y_mode == 1 && p->H != 1) return fail(c, AG_ERR_INVALID, "masked rollout has a single look-ahead step");
+    const int N = p->N_o + p->M;
+    int rc = check_topk(c, N, p->topk);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    c->prof_stream = st;
+
+    const size_t nrep = (size_t)p->B * p->H;
+    if (c->repeat_cap < nrep) {
+        if (c->d_repeat) HIPCHK(c, hipFree(c->d_repeat));
+        c->d_repeat = nullptr; c->repeat_cap = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_repeat), nrep * 4));
+        c->repeat_cap = nrep;
+    }
+    c->h_repeat.assign(h_repeat, h_repeat + nrep);
+    h_repeat = c->h_repeat.data();
+    HIPCHK(c, hipMemcpyAsync(c->d_repeat, h_repeat, nrep * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(d_state_seqs, 0, (size_t)p->B * p->H * p->N_o * 3 * 4, st));   // forward_dynamics.py:32
+
+    const int k = std::min(N, p->topk);
+    const long bound = (long)N * (k + p->M);                 // in-degree <= topk + M (radius-AND-top-k, then tool rule)
+    const int edge_cap = (int)round_up((size_t)std::min<long>(bound, p->max_nR), 256);
+    const int Bc = auto_chunk(c, p->B, N);
+    const int slices = pick_slices(Bc, N);
+    Work w{};
+    rc = make_work(c, w, Bc, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o);
+    if (rc) return rc;
+
+    for (int b0 = 0; b0 < p->B; b0 += Bc) {
+        const int nb = std::min(Bc, p->B - b0);
+        GraphBufs g = w.g;
+        g.B = nb; g.n_p = p->N_o;
+        RollArgs ra{};
+        ra.B = nb; ra.N_o = p->N_o; ra.M = p->M; ra.H = p->H; ra.y_mode = p->y_mode; ra.b0 = b0;
+        ra.grip = p->gripper_offset; ra.grip_on = p->gripper_enable; ra.phys = p->physics_param; ra.phys_vec = d_phys_vec;
+        ra.state0 = d_state0; ra.state0_batched = p->y_mode == 1; ra.obj_mask = d_obj_mask;
+        ra.eef_xz = d_eef_xz; ra.eef_delta = d_eef_delta; ra.repeat = c->d_repeat; ra.state_seqs = d_state_seqs;
+        EdgeArgs ea{};
+        ea.pos = w.r.hist + (size_t)(N_HIS - 1) * N * 3; ea.pos_bstride = (long)N_HIS * N * 3;
+        ea.mask = w.r.mask; ea.tool = w.r.tool; ea.thr_vec = nullptr; ea.thr = p->adj_thresh;
+        ea.B = nb; ea.N = N; ea.topk = p->topk; ea.cta = p->connect_tools_all ? 1 : 0; ea.edge_cap = edge_cap;
+        ea.slices = slices; ea.tstar = w.tstar; ea.deg = w.deg; ea.slice_tot = w.slice_tot; ea.cta_flag = w.cta_flag;
+        ea.recv = w.recv; ea.send = w.send; ea.row_ptr = w.row_ptr; ea.n_edges = w.n_edges;
+        ea.overflow = d_overflow_flag; ea.max_nR = p->max_nR; ea.zero_on_overflow = 1;
+        for (int li = 0; li < p->H; ++li) {
+            int max_rep = 0;
+            for (int b = 0; b < nb; ++b) max_rep = std::max(max_rep, h_repeat[(size_t)(b0 + b) * p->H + li]);
+            ra.li = li; ra.ai = 0;
+            { Scoped s(c, FAM_ROLL_INIT); HIPCHK(c, launch_roll_init(ra, w.r, g, st)); }
+            for (int ai = 1; ai <= max_rep; ++ai) {           // forward_dynamics.py:156
+                HIPCHK(c, launch_edge_build(ea, st, prof_mark, c));
+                rc = run_model(c, g, w.r.pred, w.r.motion, st);
+                if (rc) return rc;
+                ra.ai = ai;
+                { Scoped s(c, FAM_ROLL_UPDATE); HIPCHK(c, launch_roll_update(ra, w.r, g, st)); }
+            }
+        }
+    }
+    return AG_OK;
+}
+
+int ag_rollout(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0, const uint8_t* d_obj_mask,
+               const float* d_eef_xz, const float* d_eef_delta, const int32_t* h_repeat, const float* d_phys_vec,
+               float* d_state_seqs) {
+    if (!c) return AG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, st));
+    int rc = ag_rollout_async(c, stream, p, d_state0, d_obj_mask, d_eef_xz, d_eef_delta, h_repeat, d_phys_vec, d_state_seqs, c->d_overflow);
+    if (rc) return rc;
+    int seen = 0;
+    HIPCHK(c, hipMemcpyAsync(&seen, c->d_overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (seen > p->max_nR) return fail(c, AG_ERR_MAX_NR, "Exceeds max dims: a graph had %d edges, max_nR=%d", seen, p->max_nR);
+    return AG_OK;
+}
+
+int ag_ctx_set_profiling(ag_ctx* c, int32_t mask) {
+    if (!c) return AG_ERR_INVALID;
+    c->prof_mask = (unsigned)mask;
+    return AG_OK;
+}
+
+static int prof_collect(ag_ctx* c) {
+    for (auto& p : c->prof_live) {
+        hipError_t e = hipEventSynchronize(p.e1);
+        if (e != hipSuccess) return fail(c, AG_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, p.e0, p.e1);
+        if (e != hipSuccess) return fail(c, AG_ERR_HIP, "hipEventElapsedTime: %s", hipGetErrorString(e));
+        c->prof_ms[p.fam] += ms; c->prof_n[p.fam] += 1;
+        c->prof_pool.push_back(p.e0); c->prof_pool.push_back(p.e1);
+    }
+    c->prof_live.clear();
+    return AG_OK;
+}
+
+int ag_ctx_kernel_stats(ag_ctx* c, const char* kernel, double* out_ms, int64_t* out_n) {
+    if (!c || !kernel || !out_ms || !out_n) return AG_ERR_INVALID;
+    int rc = prof_collect(c);
+    if (rc) return rc;
+    for (int f = 0; f < FAM_COUNT; ++f)
+        if (!strcmp(kernel, kFamilyNames[f])) { *out_ms = c->prof_ms[f]; *out_n = c->prof_n[f]; return AG_OK; }
+    return fail(c, AG_ERR_INVALID, "unknown kernel family '%s'", kernel);
+}
+
+int ag_ctx_reset_stats(ag_ctx* c) {
+    if (!c) return AG_ERR_INVALID;
+    int rc = prof_collect(c);
+    for (int f = 0; f < FAM_COUNT; ++f) { c->prof_ms[f] = 0; c->prof_n[f] = 0; }
+    return rc;
+}
+
+}  // extern "C"

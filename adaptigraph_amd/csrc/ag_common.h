@@ -1,0 +1,128 @@
+// Shared constants and host-side declarations for the gfx950 kernels (internal, not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ag {
+
+// ---- model geometry (every shipped config: src/config/dynamics/*.yaml model_config) --------------------
+constexpr int NF = 150;        // real feature width of every hidden layer
+constexpr int NFP = 160;       // row pitch of every activation buffer (5 MFMA tiles of 32)
+constexpr int ONE_F = 150;     // slot that carries the constant 1.0 (bias rides in weight column 150)
+constexpr int N_HIS = 4;
+constexpr int IN_DIM = 6;      // [attr_obj, attr_tool, phys, act_x, act_y, act_z]
+constexpr int REL_DIM = 17;    // [attr_r(2), attr_s(2), group_diff, (res0,res1,res2,cur)_r - (...)_s]
+constexpr int F12 = 3 * N_HIS; // per-particle history feature row
+constexpr int NODE_IN = 8;     // node input row: 6 features, 1.0, pad
+
+// ---- packed weight geometry ----------------------------------------------------------------------------
+// A hidden layer consumes K = 152 input slots = 76 MFMA k-steps (v_mfma_f32_32x32x2_f32 eats 2 k per step:
+// lanes 0-31 supply k_a, lanes 32-63 supply k_b).  Step s reads accumulator register (tile t, reg r) of the
+// previous layer: t = s/16, r = s%16 (tile 4 only has r < 12), i.e. features 32t + (r&3) + 8(r>>2) + 4h.
+// Weights are packed [chunk q = s/4][m-block][lane][4 steps] so one ds_read_b128 feeds 4 MFMAs.
+constexpr int KSTEPS = 76;
+constexpr int KCH = 19;               // chunks of 4 steps
+constexpr int KCH_H0 = 10;            // chunks staged in the first half-phase
+constexpr int KCH_H1 = KCH - KCH_H0;  // 9
+constexpr int CHUNK_FLOATS_MB5 = 5 * 64 * 4;  // 1280 floats per chunk for a 160-wide output
+constexpr int CHUNK_FLOATS_MB1 = 1 * 64 * 4;
+constexpr int HALF0_FLOATS = KCH_H0 * CHUNK_FLOATS_MB5;  // 12800
+constexpr int HALF1_FLOATS = KCH_H1 * CHUNK_FLOATS_MB5;  // 11520
+constexpr int LAYER_FLOATS = HALF0_FLOATS + HALF1_FLOATS;  // 24320
+constexpr int EDGE_L1_CHUNKS = 3;     // 18 inputs -> 9 steps, padded to 12
+constexpr int NODE_L1_CHUNKS = 1;     // 8 inputs -> 4 steps
+constexpr int OUT3_FLOATS = KCH * CHUNK_FLOATS_MB1;  // predictor head (3 outputs, one m-block)
+
+// Offsets (floats) into the packed weight blob, in the order the chains stage them.
+struct WeightLayout {
+    // edge chain: L1, L2, L3, W1(+b_rp)
+    static constexpr int E_L1 = 0;
+    static constexpr int E_L2 = E_L1 + EDGE_L1_CHUNKS * CHUNK_FLOATS_MB5;
+    static constexpr int E_L3 = E_L2 + LAYER_FLOATS;
+    static constexpr int E_W1 = E_L3 + LAYER_FLOATS;
+    // node encode chain: L1, L2, L3, Wa(+b_pp), W2, W3
+    static constexpr int N_L1 = E_W1 + LAYER_FLOATS;
+    static constexpr int N_L2 = N_L1 + NODE_L1_CHUNKS * CHUNK_FLOATS_MB5;
+    static constexpr int N_L3 = N_L2 + LAYER_FLOATS;
+    static constexpr int N_WA = N_L3 + LAYER_FLOATS;
+    static constexpr int N_W2 = N_WA + LAYER_FLOATS;
+    static constexpr int N_W3 = N_W2 + LAYER_FLOATS;
+    // node propagate chain: Wb, then (W2, W3) again, or the predictor P0, P1, P2
+    static constexpr int P_WB = N_W3 + LAYER_FLOATS;
+    static constexpr int P_P0 = P_WB + LAYER_FLOATS;
+    static constexpr int P_P1 = P_P0 + LAYER_FLOATS;
+    static constexpr int P_P2 = P_P1 + LAYER_FLOATS;
+    static constexpr int TOTAL = P_P2 + OUT3_FLOATS;
+};
+
+// ---- kernel families (profiling ids) ------------------------------------------------------------------
+enum Family { FAM_EDGE_COUNT = 0, FAM_EDGE_EMIT, FAM_PREP, FAM_NODE_ENC, FAM_EDGE_ENC, FAM_MP, FAM_NODE_PROP,
+              FAM_NODE_FINAL, FAM_ROLL_INIT, FAM_ROLL_UPDATE, FAM_COUNT };
+
+// ---- launchers (defined in the .hip files) ------------------------------------------------------------
+struct EdgeArgs {
+    const float* pos;           // (B,N,3) with `pos_bstride` floats between candidates
+    long pos_bstride;
+    const uint8_t* mask;        // (B,N)
+    const uint8_t* tool;        // (B,N)
+    const float* thr_vec;       // (B,) or null
+    float thr;
+    int B, N, topk, cta, edge_cap, slices;
+    unsigned long long* tstar;  // (B,N) scratch: per-row k-th smallest key
+    int* deg;                   // (B,N) scratch
+    int* slice_tot;             // (B,slices) scratch
+    int* cta_flag;              // (B,) scratch: connect_tools_all batch flag
+    int* recv; int* send;       // (B,edge_cap)
+    int* row_ptr;               // (B,N+1)
+    int* n_edges;               // (B,)
+    int* overflow;              // single int: max edge count seen above max_nR (atomicMax), may be null
+    int max_nR;
+    int zero_on_overflow;       // internal rollout use: present an EMPTY graph downstream when E > edge_cap
+};
+hipError_t launch_edge_build(const EdgeArgs& a, hipStream_t st, void (*mark)(void*, int, int), void* mark_ctx);
+
+struct GraphBufs {
+    // per-chunk activations; node rows = b*N + i, edge rows = b*c_cap + e, pitch NFP floats
+    float* node_in;   // (B*N, NODE_IN)  [attr_obj, attr_tool, phys, act xyz, 1, 0]
+    float* feat12;    // (B*N, F12)      [res0, res1, res2, cur] (model.py:156-166)
+    float* group;     // (B*N, n_inst)   [p_instance ; 0]        (model.py:264)
+    float* eff;       // particle effect, updated in place by the propagate chain
+    float* P; float* U; float* V; float* agg;
+    float* C;         // (B*c_cap, NFP)  W1*rel_enc + b_rp
+    const int* recv; const int* send; const int* row_ptr; const int* n_edges;
+    int B, N, n_p, n_inst;
+    int edge_cap;     // pitch of recv/send per candidate
+    int c_cap;        // pitch of C per candidate, multiple of 256
+};
+hipError_t launch_node_enc(const float* wblob, const GraphBufs& g, hipStream_t st);
+hipError_t launch_edge_enc(const float* wblob, const GraphBufs& g, hipStream_t st);
+hipError_t launch_mp(const GraphBufs& g, hipStream_t st);
+hipError_t launch_node_prop(const float* wblob, const GraphBufs& g, hipStream_t st);
+hipError_t launch_node_final(const float* wblob, const GraphBufs& g, float clamp, float* pred_pos, float* pred_motion,
+                             hipStream_t st);
+
+// model-input preparation for ag_forward: state (B,n_his,N,3) etc. -> node_in, feat12
+hipError_t launch_prep(const float* state, const float* attrs, const float* action, const float* phys,
+                       const GraphBufs& g, hipStream_t st);
+
+struct RollBufs {
+    float* hist;        // (B, N_HIS, N, 3)
+    float* pred;        // (B, N_o, 3) latest prediction
+    float* motion;      // (B, N_o, 3) latest raw motion (not consumed by the rollout)
+    uint8_t* mask;      // (B,N) valid particles incl. tools
+    uint8_t* tool;      // (B,N)
+};
+struct RollArgs {
+    int B, N_o, M, H, li, ai, y_mode, b0;  // b0 = first candidate of this chunk in the full batch
+    float grip; int grip_on; float phys;
+    const float* phys_vec;                    // null or (N_o,) per-particle physics parameter
+    const float* state0; int state0_batched;  // (N_o,3) or (Bfull,N_o,3)
+    const uint8_t* obj_mask;                  // (Bfull,N_o) or null
+    const float* eef_xz; const float* eef_delta;  // (Bfull,H,M,2), (Bfull,H,M,3)
+    const int* repeat;                        // device (Bfull,H)
+    float* state_seqs;                        // (Bfull,H,N_o,3)
+};
+hipError_t launch_roll_init(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);
+hipError_t launch_roll_update(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);
+
+}  // namespace ag

@@ -1,0 +1,267 @@
+// HBM/L2-bound kernels of the rollout step: edge->node message passing with a CSR segmented sum, model-input
+// preparation, and the per-step rollout bookkeeping (tool keypoints, history shift, capture).  gfx950 only.
+#include "ag_common.h"
+
+namespace ag {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ message passing
+// agg[i] = sum over edges e with recv(e) = i of ReLU(C[e] + U[i] + V[send(e)])
+//   = Rr^T.bmm(relation_propagator([rel_enc | eff_r | eff_s]))           (reference model.py:312-324)
+// with W_rp factored as [W1|W2|W3]: C = W1*rel_enc + b, U = W2*eff, V = W3*eff.
+// One wavefront per receiver.  Edges are CSR-sorted by receiver, so the segment is contiguous; lanes map to
+// FEATURES (40 lanes x float4 = one 640-B row), so every C / V row is one coalesced read and the segmented sum
+// needs no cross-lane traffic and no atomics: each lane adds its 4 features edge after edge, in edge order.
+// Roofline: HBM/L2 bytes.  Algorithmic bytes per receiver: deg*(640 C + 640 V + 4 idx) + 640 U + 640 agg.
+constexpr int MP_WAVES = 4;
+struct MpDev {
+    const float* C; const float* U; const float* V; float* agg;
+    const int* send; const int* row_ptr;
+    int B, N, edge_cap, c_cap;
+};
+__global__ __launch_bounds__(MP_WAVES * 64) void k_mp(MpDev g) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * MP_WAVES + (threadIdx.x >> 6);
+    if (row >= (long)g.B * g.N) return;
+    const int b = (int)(row / g.N), i = (int)(row - (long)b * g.N);
+    const int e0 = g.row_ptr[(long)b * (g.N + 1) + i], e1 = g.row_ptr[(long)b * (g.N + 1) + i + 1];
+    if (lane >= NFP / 4) return;
+    const f32x4 u = reinterpret_cast<const f32x4*>(g.U + row * NFP)[lane];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int* snd = g.send + (long)b * g.edge_cap;
+    const float* Cb = g.C + (long)b * g.c_cap * NFP;
+    const float* Vb = g.V + (long)b * g.N * NFP;
+    int e = e0;
+    for (; e + 4 <= e1; e += 4) {                            // 8 independent 16-B loads in flight per lane
+        f32x4 c[4], v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = reinterpret_cast<const f32x4*>(Cb + (long)(e + k) * NFP)[lane];
+            v[k] = reinterpret_cast<const f32x4*>(Vb + (long)snd[e + k] * NFP)[lane];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc[d] += fmaxf((c[k][d] + u[d]) + v[k][d], 0.0f);
+    }
+    for (; e < e1; ++e) {
+        const f32x4 c = reinterpret_cast<const f32x4*>(Cb + (long)e * NFP)[lane];
+        const f32x4 v = reinterpret_cast<const f32x4*>(Vb + (long)snd[e] * NFP)[lane];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[d] += fmaxf((c[d] + u[d]) + v[d], 0.0f);
+    }
+    reinterpret_cast<f32x4*>(g.agg + row * NFP)[lane] = acc;
+}
+
+hipError_t launch_mp(const GraphBufs& g, hipStream_t st) {
+    MpDev d{g.C, g.U, g.V, g.agg, g.send, g.row_ptr, g.B, g.N, g.edge_cap, g.c_cap};
+    const long rows = (long)g.B * g.N;
+    hipLaunchKernelGGL(k_mp, dim3((unsigned)((rows + MP_WAVES - 1) / MP_WAVES)), dim3(MP_WAVES * 64), 0, st, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ forward() input prep
+// state (B,n_his,N,3) -> feat12 rows [res0,res1,res2,cur] (model.py:156-166); node_in rows [attrs, phys, action, 1, 0]
+// (model.py:169, 206-210, 223).
+struct PrepDev {
+    const float* state; const float* attrs; const float* action; const float* phys;
+    float* node_in; float* feat12; int B, N;
+};
+__global__ void k_prep(PrepDev p) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= (long)p.B * p.N) return;
+    const int b = (int)(row / p.N), i = (int)(row - (long)b * p.N);
+    float s[N_HIS][3];
+#pragma unroll
+    for (int h = 0; h < N_HIS; ++h)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s[h][c] = p.state[(((long)b * N_HIS + h) * p.N + i) * 3 + c];
+    float* f = p.feat12 + row * F12;
+#pragma unroll
+    for (int h = 0; h < N_HIS - 1; ++h)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[3 * h + c] = s[h + 1][c] - s[h][c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f[3 * (N_HIS - 1) + c] = s[N_HIS - 1][c];
+    float* n = p.node_in + row * NODE_IN;
+    n[0] = p.attrs[row * 2 + 0]; n[1] = p.attrs[row * 2 + 1]; n[2] = p.phys[row];
+    n[3] = p.action[row * 3 + 0]; n[4] = p.action[row * 3 + 1]; n[5] = p.action[row * 3 + 2];
+    n[6] = 1.0f; n[7] = 0.0f;
+}
+hipError_t launch_prep(const float* state, const float* attrs, const float* action, const float* phys,
+                       const GraphBufs& g, hipStream_t st) {
+    PrepDev p{state, attrs, action, phys, g.node_in, g.feat12, g.B, g.N};
+    const long rows = (long)g.B * g.N;
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ rollout bookkeeping
+struct RollDev {
+    RollArgs a;
+    float* hist; float* pred; uint8_t* mask; uint8_t* tool;
+    float* node_in; float* feat12; float* group; int n_inst;
+};
+constexpr int RT = 256;
+
+// tool height: min object y (forward_dynamics.py:40,163) or masked mean (forward_dynamics.py:235,359).
+// `src` = (N_o,3) cloud of this candidate.  Result broadcast to the whole workgroup.
+__device__ float tool_y(const float* src, const uint8_t* om, int N_o, int y_mode, float* red, int* redi) {
+    const int tid = threadIdx.x;
+    if (y_mode == 0) {
+        float m = 3.4e38f;
+        for (int i = tid; i < N_o; i += RT) m = fminf(m, src[3 * i + 1]);
+        red[tid] = m;
+        __syncthreads();
+        for (int o = RT / 2; o > 0; o >>= 1) {
+            if (tid < o) red[tid] = fminf(red[tid], red[tid + o]);
+            __syncthreads();
+        }
+        const float y = red[0];
+        __syncthreads();
+        return y;
+    }
+    float s = 0.0f; int c = 0;
+    for (int i = tid; i < N_o; i += RT) {
+        const bool v = om ? om[i] != 0 : true;
+        s += v ? src[3 * i + 1] : 0.0f;
+        c += v ? 1 : 0;
+    }
+    red[tid] = s; redi[tid] = c;
+    __syncthreads();
+    for (int o = RT / 2; o > 0; o >>= 1) {
+        if (tid < o) { red[tid] += red[tid + o]; redi[tid] += redi[tid + o]; }
+        __syncthreads();
+    }
+    const float y = red[0] / (float)redi[0];
+    __syncthreads();
+    return y;
+}
+
+// Start of look-ahead step li (forward_dynamics.py:37-123 / 225-317): object cloud = start state (li == 0) or the
+// captured prediction of step li-1; all n_his frames equal; tool keypoints from the decoded action; attrs, masks,
+// p_instance, physics parameter, action rows.
+__global__ __launch_bounds__(RT) void k_roll_init(RollDev d) {
+    __shared__ float red[RT];
+    __shared__ int redi[RT];
+    const RollArgs& a = d.a;
+    const int b = blockIdx.x, bg = a.b0 + b, tid = threadIdx.x;
+    const int N = a.N_o + a.M;
+    const float* src = a.li == 0 ? (a.state0_batched ? a.state0 + (long)bg * a.N_o * 3 : a.state0)
+                                 : a.state_seqs + ((long)bg * a.H + (a.li - 1)) * a.N_o * 3;
+    const uint8_t* om = a.obj_mask ? a.obj_mask + (long)bg * a.N_o : nullptr;
+    float y = tool_y(src, om, a.N_o, a.y_mode, red, redi);
+    if (a.grip_on) y = y + a.grip;                           // :80-81
+    int count = a.N_o;
+    if (om) {                                                // first-`count` rows carry p_instance (:294-300)
+        int c = 0;
+        for (int i = tid; i < a.N_o; i += RT) c += om[i] ? 1 : 0;
+        redi[tid] = c;
+        __syncthreads();
+        for (int o = RT / 2; o > 0; o >>= 1) { if (tid < o) redi[tid] += redi[tid + o]; __syncthreads(); }
+        count = redi[0];
+        __syncthreads();
+    }
+    for (int i = tid; i < N; i += RT) {
+        float p[3], act[3] = {0.f, 0.f, 0.f};
+        const bool is_tool = i >= a.N_o;
+        if (!is_tool) {
+            p[0] = src[3 * i]; p[1] = src[3 * i + 1]; p[2] = src[3 * i + 2];
+        } else {
+            const int m = i - a.N_o;
+            const float* xz = a.eef_xz + (((long)bg * a.H + a.li) * a.M + m) * 2;
+            const float* dl = a.eef_delta + (((long)bg * a.H + a.li) * a.M + m) * 3;
+            p[0] = xz[0]; p[1] = y; p[2] = xz[1];
+            act[0] = dl[0]; act[1] = dl[1]; act[2] = dl[2];
+        }
+        const long row = (long)b * N + i;
+#pragma unroll
+        for (int h = 0; h < N_HIS; ++h)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d.hist[(((long)b * N_HIS + h) * N + i) * 3 + c] = p[c];
+        float* f = d.feat12 + row * F12;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) f[c] = 0.0f;             // identical frames: residuals are exactly 0
+        f[9] = p[0]; f[10] = p[1]; f[11] = p[2];
+        const bool ov = is_tool ? false : (om ? om[i] != 0 : true);
+        float* n = d.node_in + row * NODE_IN;
+        n[0] = ov ? 1.0f : 0.0f;                             // attrs[:, :nobj, 0] (:92 / :287)
+        n[1] = is_tool ? 1.0f : 0.0f;                        // attrs[:, nobj:, 1] (:93)
+        n[2] = is_tool ? 0.0f : (a.phys_vec ? a.phys_vec[i] : a.phys);                      // model.py:197,206-207
+        n[3] = act[0]; n[4] = act[1]; n[5] = act[2];         // states_delta (:87-88)
+        n[6] = 1.0f; n[7] = 0.0f;
+        for (int k = 0; k < d.n_inst; ++k) d.group[row * d.n_inst + k] = (k == 0 && !is_tool && i < count) ? 1.0f : 0.0f;
+        d.mask[row] = (is_tool || ov) ? 1 : 0;               // state_mask (:107-109 / :302-304)
+        d.tool[row] = is_tool ? 1 : 0;                       // eef_mask (:111-112)
+    }
+}
+
+// After forward number ai of look-ahead step li (forward_dynamics.py:160-176 / 356-372): capture, tool advance,
+// history shift, history features for the next forward.
+__global__ __launch_bounds__(RT) void k_roll_update(RollDev d) {
+    __shared__ float red[RT];
+    __shared__ int redi[RT];
+    const RollArgs& a = d.a;
+    const int b = blockIdx.x, bg = a.b0 + b, tid = threadIdx.x;
+    const int N = a.N_o + a.M;
+    const float* pred = d.pred + (long)b * a.N_o * 3;
+    const uint8_t* om = a.obj_mask ? a.obj_mask + (long)bg * a.N_o : nullptr;
+    if (a.repeat[(long)bg * a.H + a.li] == a.ai) {           // :160-161
+        float* out = a.state_seqs + ((long)bg * a.H + a.li) * a.N_o * 3;
+        for (int k = tid; k < a.N_o * 3; k += RT) out[k] = pred[k];
+    }
+    float y = tool_y(pred, om, a.N_o, a.y_mode, red, redi);  // :163 / :359
+    if (a.grip_on) y = y + a.grip;                           // :167-168
+    for (int i = tid; i < N; i += RT) {
+        const long row = (long)b * N + i;
+        float h[N_HIS][3];
+#pragma unroll
+        for (int k = 0; k < N_HIS; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) h[k][c] = d.hist[(((long)b * N_HIS + k) * N + i) * 3 + c];
+        float nw[3];
+        if (i < a.N_o) {
+            nw[0] = pred[3 * i]; nw[1] = pred[3 * i + 1]; nw[2] = pred[3 * i + 2];     // :170
+        } else {
+            const float* act = d.node_in + row * NODE_IN + 3;
+            nw[0] = h[N_HIS - 1][0] + act[0];                                          // :164
+            nw[1] = y;                                                                 // :166
+            nw[2] = h[N_HIS - 1][2] + act[2];
+        }
+#pragma unroll
+        for (int k = 0; k < N_HIS - 1; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) h[k][c] = h[k + 1][c];                         // :176
+#pragma unroll
+        for (int c = 0; c < 3; ++c) h[N_HIS - 1][c] = nw[c];
+#pragma unroll
+        for (int k = 0; k < N_HIS; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d.hist[(((long)b * N_HIS + k) * N + i) * 3 + c] = h[k][c];
+        float* f = d.feat12 + row * F12;
+#pragma unroll
+        for (int k = 0; k < N_HIS - 1; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) f[3 * k + c] = h[k + 1][c] - h[k][c];          // model.py:156
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[9 + c] = h[N_HIS - 1][c];
+    }
+}
+
+static RollDev to_dev(const RollArgs& a, const RollBufs& r, const GraphBufs& g) {
+    RollDev d;
+    d.a = a; d.hist = r.hist; d.pred = r.pred; d.mask = r.mask; d.tool = r.tool;
+    d.node_in = g.node_in; d.feat12 = g.feat12; d.group = g.group; d.n_inst = g.n_inst;
+    return d;
+}
+hipError_t launch_roll_init(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st) {
+    hipLaunchKernelGGL(k_roll_init, dim3(a.B), dim3(RT), 0, st, to_dev(a, r, g));
+    return hipGetLastError();
+}
+hipError_t launch_roll_update(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st) {
+    hipLaunchKernelGGL(k_roll_update, dim3(a.B), dim3(RT), 0, st, to_dev(a, r, g));
+    return hipGetLastError();
+}
+
+}  // namespace ag

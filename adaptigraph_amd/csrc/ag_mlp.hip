@@ -1,0 +1,367 @@
+// Fused MLP chains on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950 only.
+//
+// Replaces Encoder / Propagator / ParticlePredictor forwards (reference src/dynamics/gnn/model.py:4-61) and the
+// feature assembly + dense one-hot bmm gathers around them (model.py:152-294, 312-330, 335-338).
+//
+// Design (MI355X-first, not a translation of nn.Linear + bmm):
+//   * The transposed problem Y^T = W * X^T is computed: the MFMA A operand is a 32(out-feature) x 2(k) weight
+//     sliver, the B operand is 2(k) x 32(rows).  A wavefront owns 32 rows (edges or particles); after a layer the
+//     accumulator holds, for row = lane&31, output features spread over its 80 registers (5 tiles x 16) and the
+//     two lane halves.  That IS the B-operand layout of the next layer (k on lane-half, row on lane&31) - so a
+//     whole Linear-ReLU-Linear-... chain runs with activations never leaving registers: no LDS round trip, no
+//     cross-lane movement.  The K order this implies (feature 32t + (r&3) + 8(r>>2) + 4h for register (t,r),
+//     half h) is baked into the host-side weight packing (ag_api.hip: pack_layer).
+//   * Bias rides in the contraction: activation slot 150 is forced to 1.0, weight column 150 holds the bias.
+//   * The 160x152 weight panel of a layer (95 KB) is shared by the 8 wavefronts of a 512-thread workgroup through
+//     LDS, staged in two K-halves so the next half streams global->registers->LDS underneath the MFMAs of the
+//     current half (two 50 KB buffers).  One ds_read_b128 feeds 4 MFMAs per m-block.
+//   * Roofline: fp32 MFMA (157.3 TFLOP/s).  Per 32 rows a 160-wide layer is 380 MFMAs = 2*32*160*152 FLOP.
+//   * Rows are independent columns of the MFMA, so results do not depend on which lane / workgroup / chunk / GPU a
+//     row lands in: sharded == unsharded bit-for-bit.
+#include "ag_common.h"
+
+namespace ag {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG = 512;
+constexpr int WG_ROWS = 256;
+constexpr int BUF_FLOATS = HALF0_FLOATS;   // one LDS staging buffer (51,200 B)
+
+struct Act { f32x16 t[5]; };
+
+// ------------------------------------------------------------------------------------------------ staging
+template <int NFLOATS>
+struct Stager {
+    static constexpr int N4 = NFLOATS / 4;
+    static constexpr int NV = (N4 + WG - 1) / WG;
+    f32x4 v[NV > 0 ? NV : 1];
+    __device__ __forceinline__ void load(const float* __restrict__ src, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * WG;
+            if ((i + 1) * WG <= N4 || idx < N4) v[i] = reinterpret_cast<const f32x4*>(src)[idx];
+        }
+    }
+    __device__ __forceinline__ void store(float* dst, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * WG;
+            if ((i + 1) * WG <= N4 || idx < N4) reinterpret_cast<f32x4*>(dst)[idx] = v[i];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ MFMA sweeps
+// chunks [Q0,Q1) of a layer whose LDS image starts at chunk Q0; input = previous accumulator tiles
+template <int Q0, int Q1, int MB>
+__device__ __forceinline__ void mma_act(const float* wl, const Act& in, f32x16* acc, int lane) {
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q) {
+        f32x4 a[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            a[mb] = *reinterpret_cast<const f32x4*>(wl + ((q - Q0) * MB + mb) * 256 + lane * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s = 4 * q + e;
+            const int t = s < 64 ? s / 16 : 4;
+            const int r = s < 64 ? s % 16 : s - 64;
+            const float b = in.t[t][r];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][e], b, acc[mb], 0, 0, 0);
+        }
+    }
+}
+
+// first layer: input features f[0 .. 8*NCH) held per lane; step s consumes (f[2s], f[2s+1]) on the two lane halves
+template <int NCH>
+__device__ __forceinline__ void mma_feat(const float* wl, const float* f, f32x16* acc, int lane) {
+    const bool hi = lane >= 32;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        f32x4 a[5];
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb) a[mb] = *reinterpret_cast<const f32x4*>(wl + (q * 5 + mb) * 256 + lane * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int s = 4 * q + e;
+            const float b = hi ? f[2 * s + 1] : f[2 * s];
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][e], b, acc[mb], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void zero(Act& a) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.t[t][r] = 0.0f;
+}
+__device__ __forceinline__ void relu_one(Act& a, int lane) {   // ReLU, then force slot 150 (tile 4, reg 10, upper half) to 1
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.t[t][r] = __builtin_fmaxf(a.t[t][r], 0.0f);
+    a.t[4][10] = lane >= 32 ? 1.0f : a.t[4][10];
+}
+__device__ __forceinline__ void set_one(Act& a, int lane) { a.t[4][10] = lane >= 32 ? 1.0f : a.t[4][10]; }
+
+// row-major (pitch NFP) <-> accumulator layout.  Lane (j = lane&31, h = lane>>5) owns, of row j, the 16-byte
+// groups at feature 32t + 8q + 4h (registers 4q..4q+3 of tile t).
+__device__ __forceinline__ void load_rows(Act& a, const float* __restrict__ base, long row, int lane) {
+    const float* p = base + row * NFP + 4 * (lane >> 5);
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + 32 * t + 8 * q);
+            a.t[t][4 * q + 0] = v[0]; a.t[t][4 * q + 1] = v[1]; a.t[t][4 * q + 2] = v[2]; a.t[t][4 * q + 3] = v[3];
+        }
+}
+__device__ __forceinline__ void add_rows(Act& a, const float* __restrict__ base, long row, int lane) {
+    const float* p = base + row * NFP + 4 * (lane >> 5);
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + 32 * t + 8 * q);
+            a.t[t][4 * q + 0] += v[0]; a.t[t][4 * q + 1] += v[1]; a.t[t][4 * q + 2] += v[2]; a.t[t][4 * q + 3] += v[3];
+        }
+}
+__device__ __forceinline__ void store_rows(const Act& a, float* __restrict__ base, long row, int lane, bool valid) {
+    if (!valid) return;
+    float* p = base + row * NFP + 4 * (lane >> 5);
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+            v[0] = a.t[t][4 * q + 0]; v[1] = a.t[t][4 * q + 1]; v[2] = a.t[t][4 * q + 2]; v[3] = a.t[t][4 * q + 3];
+            *reinterpret_cast<f32x4*>(p + 32 * t + 8 * q) = v;
+        }
+}
+
+// One full 160-wide layer.  Precondition: its K-half 0 is in LDS buffer 0 and a barrier has passed.
+// Streams K-half 1 into buffer 1 under the first sweep and the NEXT phase (NEXT floats from `next`) into buffer 0
+// under the second.  Postcondition: `next` is in buffer 0 and a barrier has passed (if NEXT > 0).
+template <int NEXT>
+__device__ __forceinline__ void layer160(float* lds, const float* __restrict__ w, const float* __restrict__ next,
+                                         const Act& in, Act& out, int tid, int lane) {
+    Stager<HALF1_FLOATS> s1;
+    s1.load(w + HALF0_FLOATS, tid);
+    zero(out);
+    mma_act<0, KCH_H0, 5>(lds, in, out.t, lane);
+    s1.store(lds + BUF_FLOATS, tid);
+    __syncthreads();
+    Stager<NEXT> s2;
+    if (NEXT > 0) s2.load(next, tid);
+    mma_act<KCH_H0, KCH, 5>(lds + BUF_FLOATS, in, out.t, lane);
+    if (NEXT > 0) {
+        s2.store(lds, tid);
+        __syncthreads();
+    }
+}
+
+template <int NFLOATS>
+__device__ __forceinline__ void stage_now(float* dst, const float* __restrict__ src, int tid) {
+    Stager<NFLOATS> s;
+    s.load(src, tid);
+    s.store(dst, tid);
+    __syncthreads();
+}
+
+struct GDev {
+    const float* w;
+    const float* node_in; const float* feat12; const float* group;
+    float* eff; float* P; float* U; float* V; float* agg; float* C;
+    const int* recv; const int* send; const int* row_ptr; const int* n_edges;
+    int B, N, n_p, n_inst, edge_cap, c_cap;
+    float clamp; float* pred_pos; float* pred_motion;
+};
+
+using WL = WeightLayout;
+
+// ------------------------------------------------------------------------------------------------ edge chain
+// rel_inputs (17) -> Encoder(17,150,150) -> W1*enc + b_rp  => C      (model.py:249-282, 303, 317-318 first block)
+__global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long wg_row0 = (long)blockIdx.x * WG_ROWS;
+    const int b = (int)(wg_row0 / g.c_cap);
+    const int e0 = (int)(wg_row0 - (long)b * g.c_cap);
+    const int ne = g.n_edges[b];
+    if (e0 >= ne) return;                                    // whole workgroup past this candidate's edges
+
+    // small first-layer panel -> buffer 1; under its MFMAs, L2 half 0 -> buffer 0
+    stage_now<EDGE_L1_CHUNKS * CHUNK_FLOATS_MB5>(lds + BUF_FLOATS, g.w + WL::E_L1, tid);
+    Stager<HALF0_FLOATS> sn;
+    sn.load(g.w + WL::E_L2, tid);
+
+    const int el = e0 + wave * 32 + (lane & 31);
+    const bool valid = el < ne;
+    const int elc = valid ? el : 0;
+    const int r = g.recv[(long)b * g.edge_cap + elc], s = g.send[(long)b * g.edge_cap + elc];
+    const long pr = (long)b * g.N + r, ps = (long)b * g.N + s;
+    float f[8 * EDGE_L1_CHUNKS];
+    {
+        const float* nr = g.node_in + pr * NODE_IN; const float* nsnd = g.node_in + ps * NODE_IN;
+        f[0] = nr[0]; f[1] = nr[1]; f[2] = nsnd[0]; f[3] = nsnd[1];            // attrs_r, attrs_s   model.py:253-254
+        float gd = 0.0f;
+        for (int k = 0; k < g.n_inst; ++k) gd += fabsf(g.group[pr * g.n_inst + k] - g.group[ps * g.n_inst + k]);
+        f[4] = gd;                                                               // model.py:264-267
+        const f32x4* fr = reinterpret_cast<const f32x4*>(g.feat12 + pr * F12);
+        const f32x4* fs = reinterpret_cast<const f32x4*>(g.feat12 + ps * F12);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const f32x4 a = fr[q], c = fs[q];
+            f[5 + 4 * q + 0] = a[0] - c[0]; f[5 + 4 * q + 1] = a[1] - c[1];     // pos_r - pos_s       model.py:277-279
+            f[5 + 4 * q + 2] = a[2] - c[2]; f[5 + 4 * q + 3] = a[3] - c[3];
+        }
+        f[17] = 1.0f;
+#pragma unroll
+        for (int k = 18; k < 8 * EDGE_L1_CHUNKS; ++k) f[k] = 0.0f;
+    }
+    Act x, y;
+    zero(y);
+    mma_feat<EDGE_L1_CHUNKS>(lds + BUF_FLOATS, f, y.t, lane);
+    sn.store(lds, tid);
+    __syncthreads();
+    relu_one(y, lane);
+    layer160<HALF0_FLOATS>(lds, g.w + WL::E_L2, g.w + WL::E_L3, y, x, tid, lane);
+    relu_one(x, lane);
+    layer160<HALF0_FLOATS>(lds, g.w + WL::E_L3, g.w + WL::E_W1, x, y, tid, lane);
+    relu_one(y, lane);
+    layer160<0>(lds, g.w + WL::E_W1, nullptr, y, x, tid, lane);
+    store_rows(x, g.C, (long)b * g.c_cap + el, lane, valid);
+}
+
+// ------------------------------------------------------------------------------------------------ node encode chain
+// p_inputs (6) -> Encoder(6,150,150) = p_enc => eff;  P = Wa*p_enc + b_pp;  U = W2*p_enc;  V = W3*p_enc
+// (model.py:297-298 and the particle_effect-dependent blocks of :317-318 / the particle_encode block of :328-330)
+__global__ __launch_bounds__(WG, 2) void k_node_enc(GDev g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long nrows = (long)g.B * g.N;
+    const long row = (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
+    const bool valid = row < nrows;
+    const long rowc = valid ? row : nrows - 1;
+
+    stage_now<NODE_L1_CHUNKS * CHUNK_FLOATS_MB5>(lds + BUF_FLOATS, g.w + WL::N_L1, tid);
+    Stager<HALF0_FLOATS> sn;
+    sn.load(g.w + WL::N_L2, tid);
+    float f[8];
+    {
+        const f32x4* p = reinterpret_cast<const f32x4*>(g.node_in + rowc * NODE_IN);
+        const f32x4 a = p[0], c = p[1];
+        f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = c[0]; f[5] = c[1]; f[6] = c[2]; f[7] = c[3];
+    }
+    Act x, y;
+    zero(y);
+    mma_feat<NODE_L1_CHUNKS>(lds + BUF_FLOATS, f, y.t, lane);
+    sn.store(lds, tid);
+    __syncthreads();
+    relu_one(y, lane);
+    layer160<HALF0_FLOATS>(lds, g.w + WL::N_L2, g.w + WL::N_L3, y, x, tid, lane);
+    relu_one(x, lane);
+    layer160<HALF0_FLOATS>(lds, g.w + WL::N_L3, g.w + WL::N_WA, x, y, tid, lane);
+    relu_one(y, lane);                                       // y = p_enc (slot 150 = 1 for the bias of Wa)
+    store_rows(y, g.eff, row, lane, valid);
+    layer160<HALF0_FLOATS>(lds, g.w + WL::N_WA, g.w + WL::N_W2, y, x, tid, lane);
+    store_rows(x, g.P, row, lane, valid);
+    layer160<HALF0_FLOATS>(lds, g.w + WL::N_W2, g.w + WL::N_W3, y, x, tid, lane);
+    store_rows(x, g.U, row, lane, valid);
+    layer160<0>(lds, g.w + WL::N_W3, nullptr, y, x, tid, lane);
+    store_rows(x, g.V, row, lane, valid);
+}
+
+// ------------------------------------------------------------------------------------------------ propagate chain
+// eff <- ReLU(Wb*agg + P + eff)   (model.py:328-330; P carries Wa*p_enc + b_pp)
+//   not last: U = W2*eff, V = W3*eff for the next round (model.py:312-318)
+//   last:     motion = ParticlePredictor(eff) (model.py:44-61, 335); pred = cur + clamp(motion) (model.py:338)
+template <bool LAST>
+__global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long nrows = (long)g.B * g.N;
+    const long row = (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
+    const bool valid = row < nrows;
+    const long rowc = valid ? row : nrows - 1;
+
+    Stager<HALF0_FLOATS> sn;
+    sn.load(g.w + WL::P_WB, tid);
+    Act x, y;
+    load_rows(x, g.agg, rowc, lane);
+    sn.store(lds, tid);
+    __syncthreads();
+    layer160<HALF0_FLOATS>(lds, g.w + WL::P_WB, g.w + (LAST ? WL::P_P0 : WL::N_W2), x, y, tid, lane);
+    add_rows(y, g.P, rowc, lane);
+    add_rows(y, g.eff, rowc, lane);
+    relu_one(y, lane);                                       // y = new particle effect (slot 150 forced to 1)
+    if (!LAST) {
+        store_rows(y, g.eff, row, lane, valid);
+        layer160<HALF0_FLOATS>(lds, g.w + WL::N_W2, g.w + WL::N_W3, y, x, tid, lane);
+        store_rows(x, g.U, row, lane, valid);
+        layer160<0>(lds, g.w + WL::N_W3, nullptr, y, x, tid, lane);
+        store_rows(x, g.V, row, lane, valid);
+    } else {
+        layer160<HALF0_FLOATS>(lds, g.w + WL::P_P0, g.w + WL::P_P1, y, x, tid, lane);
+        relu_one(x, lane);
+        layer160<OUT3_FLOATS>(lds, g.w + WL::P_P1, g.w + WL::P_P2, x, y, tid, lane);
+        relu_one(y, lane);
+        f32x16 m[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[0][r] = 0.0f;
+        mma_act<0, KCH, 1>(lds, y, m, lane);
+        // motion xyz = output features 0,1,2 = registers 0,1,2 of lanes 0..31
+        const int b = (int)(rowc / g.N), i = (int)(rowc - (long)b * g.N);
+        if (valid && lane < 32 && i < g.n_p) {
+            const float* cur = g.feat12 + rowc * F12 + 9;    // state[:, -1]  (model.py:338)
+            const long o = ((long)b * g.n_p + i) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float mo = m[0][c];
+                g.pred_motion[o + c] = mo;
+                g.pred_pos[o + c] = cur[c] + fminf(fmaxf(mo, -g.clamp), g.clamp);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static GDev to_dev(const float* w, const GraphBufs& g) {
+    GDev d;
+    d.w = w; d.node_in = g.node_in; d.feat12 = g.feat12; d.group = g.group; d.eff = g.eff; d.P = g.P; d.U = g.U;
+    d.V = g.V; d.agg = g.agg; d.C = g.C; d.recv = g.recv; d.send = g.send; d.row_ptr = g.row_ptr;
+    d.n_edges = g.n_edges; d.B = g.B; d.N = g.N; d.n_p = g.n_p; d.n_inst = g.n_inst; d.edge_cap = g.edge_cap;
+    d.c_cap = g.c_cap; d.clamp = 0; d.pred_pos = nullptr; d.pred_motion = nullptr;
+    return d;
+}
+static int node_grid(const GraphBufs& g) { return (int)(((long)g.B * g.N + WG_ROWS - 1) / WG_ROWS); }
+
+hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
+    const long rows = (long)g.B * g.c_cap;
+    hipLaunchKernelGGL(k_edge_enc, dim3((unsigned)(rows / WG_ROWS)), dim3(WG), 0, st, to_dev(w, g));
+    return hipGetLastError();
+}
+hipError_t launch_node_enc(const float* w, const GraphBufs& g, hipStream_t st) {
+    hipLaunchKernelGGL(k_node_enc, dim3(node_grid(g)), dim3(WG), 0, st, to_dev(w, g));
+    return hipGetLastError();
+}
+hipError_t launch_node_prop(const float* w, const GraphBufs& g, hipStream_t st) {
+    hipLaunchKernelGGL(k_node_prop<false>, dim3(node_grid(g)), dim3(WG), 0, st, to_dev(w, g));
+    return hipGetLastError();
+}
+hipError_t launch_node_final(const float* w, const GraphBufs& g, float clamp, float* pred_pos, float* pred_motion,
+                             hipStream_t st) {
+    GDev d = to_dev(w, g);
+    d.clamp = clamp; d.pred_pos = pred_pos; d.pred_motion = pred_motion;
+    hipLaunchKernelGGL(k_node_prop<true>, dim3(node_grid(g)), dim3(WG), 0, st, d);
+    return hipGetLastError();
+}
+
+}  // namespace ag

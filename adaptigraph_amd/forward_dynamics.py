@@ -1,0 +1,120 @@
+"""dynamics() / dynamics_masked(): the callables the planner binds with functools.partial
+(reference src/planning/plan.py:190, src/planning/real_world/planner.py:246,270,
+src/planning/physics_param_optimizer.py:219).  Same signatures and return dicts as
+src/planning/forward_dynamics.py:12-205 and :209-399.
+
+Host side (this file): decode the action batch and lay out the tool keypoints with torch CPU ops, spelled as the
+reference spells them so every cos/sin/multiply rounds identically; everything after that - graph build, GNN
+forward, tool advance, history shift, capture - runs inside ONE C-ABI call with no host sync per step.
+
+Deviations, both on paths that do not change any returned value:
+  * candidates are advanced only while some candidate of their launch chunk is still live; the reference steps
+    the whole batch to the batch maximum of action_repeat and discards the surplus (:156-161).
+  * "Exceeds max dims" is raised when a graph that is actually CONSUMED by a forward has more than max_nR edges.
+    The reference also pads (and can raise on) the graph it rebuilds after the last repeat, which nothing reads
+    (:171-174), and checks the batch max including already-captured candidates.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .context import ptr, current_stream, _require_gpu
+from .model import DynamicsPredictor
+from .plan_utils import decode_action
+
+
+def _tool_layout(decoded, theta, task_config):
+    """forward_dynamics.py:42-78 / :237-273 for every look-ahead step at once (CPU tensors).
+    decoded (B,H,4), theta (B,H) -> eef_xz (B,H,M,2), eef_delta (B,H,M,3)."""
+    pts = task_config["pusher_points"]
+    ratio = task_config["sim_real_ratio"]
+    B, H = theta.shape
+    M = len(pts)
+    if M not in (1, 5):
+        raise NotImplementedError("pusher not implemented")
+    xz = torch.zeros((B, H, M, 2))
+    delta = torch.zeros((B, H, M, 3))
+    delta[..., 0] = (decoded[..., 2] - decoded[..., 0]).unsqueeze(-1)
+    delta[..., 2] = (decoded[..., 3] - decoded[..., 1]).unsqueeze(-1)
+    xz[:, :, 0, 0] = decoded[..., 0]
+    xz[:, :, 0, 1] = decoded[..., 1]
+    for k in range(1, M):
+        xz[:, :, k, 0] = decoded[..., 0] + float(pts[k][1]) * ratio * torch.sin(theta)
+        xz[:, :, k, 1] = decoded[..., 1] - float(pts[k][1]) * ratio * torch.cos(theta)
+    return xz, delta
+
+
+def _physics(ppm_optimizer, physics_param, N_o, dev):
+    material_dims = ppm_optimizer.material_dims
+    physics_param = ppm_optimizer.physics_param if physics_param is None else physics_param
+    assert len(material_dims) == 1          # the model asserts exactly one *_physics_param key (model.py:186-187)
+    (name, _dim), = material_dims.items()
+    if name not in physics_param:
+        return 0.0, None                    # forward_dynamics.py:152-153 zeros
+    v = physics_param[name].detach().to("cpu", torch.float32).reshape(-1)
+    if v.numel() == 1:
+        return float(v[0]), None
+    assert v.numel() == N_o                 # model.py:204 reshape(B, n_p, 1)
+    return 0.0, v.to(dev).contiguous()
+
+
+def _run(model, dev, task, ppm_optimizer, physics_param, B, H, N_o, y_mode, state0, obj_mask, xz, delta, repeat,
+         sync=True, overflow_flag=None):
+    if not isinstance(model, DynamicsPredictor):
+        raise TypeError("model must be an adaptigraph_amd.DynamicsPredictor")
+    eng = model.engine(dev)
+    M = ppm_optimizer.eef_num
+    assert xz.shape[2] == M
+    grip = bool(task["gripper_enable"])
+    phys_val, phys_vec = _physics(ppm_optimizer, physics_param, N_o, dev)
+    adj = ppm_optimizer.adj_thresh
+    p = _lib.AgRolloutParams(B, H, N_o, M, int(task["topk"]), int(bool(task["connect_tools_all"])),
+                             int(task["max_nR"]), y_mode, float(adj), float(0.01 * task["sim_real_ratio"]) if grip else 0.0,
+                             int(grip), phys_val)
+    xz_d = xz.to(torch.float32).contiguous().to(dev)
+    delta_d = delta.to(torch.float32).contiguous().to(dev)
+    rep = repeat.to("cpu", torch.int32).contiguous()
+    out = torch.empty((B, H, N_o, 3), device=dev, dtype=torch.float32)
+    args = [eng.ctx, current_stream(dev), C.byref(p), ptr(state0), ptr(obj_mask), ptr(xz_d), ptr(delta_d),
+            C.c_void_p(rep.data_ptr()), ptr(phys_vec), ptr(out)]
+    if sync:
+        eng.check(eng.lib.ag_rollout(*args))
+    else:
+        eng.check(eng.lib.ag_rollout_async(*args, ptr(overflow_flag)))
+    return out
+
+
+@torch.no_grad()
+def dynamics(state, action, model, device, ppm_optimizer, physics_param=None, _sync=True, _overflow_flag=None):
+    """state (N_o,3), action (B,H,4) -> {'state_seqs': (B,H,N_o,3), 'action_seqs': (B,H,4)}"""
+    task = ppm_optimizer.task_config
+    dev = _require_gpu(device)
+    B, H = action.shape[0], action.shape[1]
+    action_cpu = action.detach().to("cpu", torch.float32)
+    decoded, repeat = decode_action(action_cpu, push_length=task["push_length"])          # :23
+    xz, delta = _tool_layout(decoded, action_cpu[:, :, 2], task)
+    state0 = state.detach().to(dev, torch.float32).contiguous()
+    N_o = state0.shape[0]
+    out = _run(model, dev, task, ppm_optimizer, physics_param, B, H, N_o, 0, state0, None, xz, delta, repeat,
+               sync=_sync, overflow_flag=_overflow_flag)
+    return {"state_seqs": out, "action_seqs": decoded.to(action.device)}
+
+
+@torch.no_grad()
+def dynamics_masked(state_init, state_mask, action, model, device, ppm_optimizer, physics_param=None):
+    """state_init (B,max_nobj,3), state_mask (B,max_nobj) bool, action (B,4)
+    -> {'state_seqs': (B,max_nobj,3), 'action_seqs': (B,4)}"""
+    task = ppm_optimizer.task_config
+    dev = _require_gpu(device)
+    B = state_init.shape[0]
+    action_cpu = action.detach().to("cpu", torch.float32)[:, None]                         # :218
+    decoded, repeat = decode_action(action_cpu, push_length=task["push_length"])
+    xz, delta = _tool_layout(decoded, action_cpu[:, :, 2], task)
+    state0 = state_init.detach().to(dev, torch.float32).contiguous()
+    N_o = state0.shape[1]
+    mask_u8 = state_mask.detach().to(dev).to(torch.bool).contiguous().view(torch.uint8)
+    out = _run(model, dev, task, ppm_optimizer, physics_param, B, 1, N_o, 1, state0, mask_u8, xz, delta, repeat)
+    return {"state_seqs": out[:, 0], "action_seqs": decoded[:, 0].to(action.device)}

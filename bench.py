@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rollout-steps/s of the GNN-dynamics rollout (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[3]): cloth, 1024 MPC candidates x 20 rollout steps
+(2 look-ahead steps x action_repeat 10) x 2025 object particles + 1 gripper particle, graph rebuilt every
+step, random-init weights, synthetic jittered 45x45 cloth.  One "step" of this bench = one dynamics() call over
+the whole candidate batch + per-candidate cost (+ RCCL all-gather of the costs when N > 1).
+Candidates are independent, so they are sharded over ranks (STRONG scaling: the 1024-candidate batch is fixed);
+the only collective is the all-gather of B/N fp32 costs per rank.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# FLOPs of the formulation the kernels execute (factored W_rp / W_pp; SURVEY §8(d) F_min), padding not counted
+FLOP_PER_EDGE = 2 * (17 * 150 + 2 * 150 * 150) + 2 * 150 * 150                     # relation encoder + W1  = 140,100
+FLOP_PER_NODE_ENC = 2 * (6 * 150 + 2 * 150 * 150) + 3 * 2 * 150 * 150              # particle encoder + Wa,W2,W3
+FLOP_PER_NODE_PROP = 3 * 2 * 150 * 150                                             # Wb + W2 + W3 (per round)
+FLOP_PER_NODE_FINAL = 2 * 150 * 150 + 2 * (2 * 150 * 150 + 3 * 150)                # Wb + predictor
+PEAK_FP32_MFMA_TFLOPS = 157.3                                                      # MI355X_MICROARCH.md chip table
+
+
+def cloth_cloud(side, rng):
+    g = (np.arange(side) - (side - 1) / 2.0) * 0.3
+    xx, zz = np.meshgrid(g, g, indexing="ij")
+    p = np.stack([xx.ravel() - 2.0, np.zeros(side * side), zz.ravel() + 1.0], 1)
+    return (p + rng.normal(0, 0.02, p.shape)).astype(np.float32)
+
+
+def make_task(max_nR):
+    return dict(adj_thresh=0.75, topk=5, connect_tools_all=True, sim_real_ratio=10, push_length=0.1,
+                gripper_enable=True, max_n=1, max_nR=max_nR, n_his=4, eef_num=1, material="cloth",
+                pusher_points=[[0.0, 0.0, 0.170]], material_dims={"cloth": 1}, material_indices={"cloth": 0})
+
+
+def model_cfg():
+    mc = dict(verbose=False, nf_particle=150, nf_relation=150, nf_effect=150, nf_physics=10, attr_dim=2, state_dim=0,
+              offset_dim=0, action_dim=3, density_dim=0, pstep=3, sequence_len=4, rel_particle_dim=0, rel_attr_dim=2,
+              rel_group_dim=1, rel_distance_dim=3, rel_density_dim=0)
+    mat = {"material_index": {"cloth": 0}, "cloth": {"physics_params": [{"name": "sf", "use": True}]}}
+    return mc, mat, {"n_his": 4, "materials": ["cloth"]}
+
+
+def make_actions(B, H, repeat, cloud, rng):
+    a = np.zeros((B, H, 4), np.float32)
+    c = cloud.mean(0)
+    a[..., 0] = c[0] + rng.uniform(-2.0, 2.0, (B, H))
+    a[..., 1] = c[2] + rng.uniform(-2.0, 2.0, (B, H))
+    a[..., 2] = rng.uniform(-3.14, 3.14, (B, H))
+    a[..., 3] = repeat + 0.5
+    return a
+
+
+def cpu_baseline(cloud, task, W, seconds=12.0):
+    """The numpy oracle (CPU restatement of the reference, oracle/) on a bounded sample of the same workload."""
+    from oracle import adaptigraph_oracle as O
+    rng = np.random.default_rng(1)
+    act = make_actions(1, 1, 2, cloud, rng)
+    t0 = time.time()
+    steps = 0
+    while True:
+        O.dynamics(W, 3, cloud, act, task)
+        steps += 2
+        if time.time() - t0 > seconds:
+            break
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:  # noqa: BLE001
+        cores = os.cpu_count() or 1
+    return {"value": steps / dt, "unit": "rollout-steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"numpy oracle, cloth 2025+1 particles, 1 candidate x {steps} rollout steps in {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--candidates", type=int, default=1024)
+    ap.add_argument("--side", type=int, default=45, help="cloth grid side (45 -> 2025 particles)")
+    ap.add_argument("--lookahead", type=int, default=2)
+    ap.add_argument("--repeat", type=int, default=10)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel family (adds overhead)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import adaptigraph_amd as ag
+    from oracle import adaptigraph_oracle as O   # weights generator + cpu_baseline only; never on the timed path
+
+    rng = np.random.default_rng(0)
+    cloud = cloth_cloud(args.side, rng)
+    N_o = cloud.shape[0]
+    B, H, R = args.candidates, args.lookahead, args.repeat
+    task = make_task(max_nR=int(1.2 * 6 * (N_o + 1)) + 64)
+    Wt = O.random_weights(0)
+    model = ag.DynamicsPredictor(*model_cfg(), dev)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in Wt.items()})
+    ppm = types.SimpleNamespace(task_config=task, eef_num=1, material="cloth", material_dims=task["material_dims"],
+                                material_indices=task["material_indices"],
+                                physics_param={"cloth": torch.tensor([0.5])}, adj_thresh=task["adj_thresh"])
+    actions = torch.from_numpy(make_actions(B, H, R, cloud, rng))      # every rank draws the same full batch
+    lo, hi = rank * B // world, (rank + 1) * B // world                # contiguous shard
+    a_local = actions[lo:hi].to(dev)
+    state0 = torch.from_numpy(cloud).to(dev)
+    target = state0.mean(0) + torch.tensor([0.5, 0.0, 0.5], device=dev)
+    eng = model.engine(dev)
+    if args.chunk:
+        eng.set_chunk(args.chunk)
+    flag = torch.zeros(64, dtype=torch.int32, device=dev)
+
+    def one_step():
+        out = ag.dynamics(state0, a_local, model, dev, ppm, _sync=False, _overflow_flag=flag)
+        seq = out["state_seqs"]                                        # (b, H, N_o, 3)
+        cost = (seq[:, -1] - target).norm(dim=-1).mean(-1)             # per-candidate running cost (stand-in)
+        if world > 1:
+            allc = torch.empty(B, device=dev)
+            dist.all_gather_into_tensor(allc, cost.contiguous())       # RCCL over xGMI: B/N fp32 per rank
+            return allc
+        return cost
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync_all()
+    fams = ["edge_enc"] if not args.profile_all else ["edge_count", "edge_emit", "node_enc", "edge_enc", "mp",
+                                                       "node_prop", "node_final", "roll_init", "roll_update"]
+    eng.reset_stats()
+    eng.set_profiling(fams)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        costs = one_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    eng.set_profiling([])
+    assert int(flag[0].item()) <= task["max_nR"], "a graph exceeded max_nR during the bench"
+    assert torch.isfinite(costs).all()
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    ms_edge, n_edge = eng.kernel_stats("edge_enc")
+    fam_ms = {f: eng.kernel_stats(f) for f in fams}
+    if rank == 0:
+        # edges per graph: measured on the start graph of candidate 0 (constant to within a few edges over the rollout)
+        mask = torch.ones((1, N_o + 1), dtype=torch.bool, device=dev)
+        tool = torch.zeros((1, N_o + 1), dtype=torch.bool, device=dev)
+        tool[:, N_o:] = True
+        pos = torch.cat([state0, torch.tensor([[float(a_local[0, 0, 0]), float(state0[:, 1].min()) + 0.1,
+                                                float(a_local[0, 0, 1])]], device=dev)])[None]
+        E = int(ag.construct_edges_index(pos, task["adj_thresh"], mask, tool, task["topk"], True).n_edges[0])
+        total_steps = B * H * R
+        launches_per_step = max(1, n_edge // max(1, args.steps))
+        edges_per_launch = E * (hi - lo) * H * R / launches_per_step
+        avg_ms = ms_edge / max(1, n_edge)
+        achieved = FLOP_PER_EDGE * edges_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        line = {
+            "metric": "rollout-steps/sec", "value": total_steps * args.steps / dt, "unit": "rollout-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: cloth, 1024 candidates x 20 rollout steps (2 look-ahead x "
+                                   "repeat 10) x 2025+1 particles, radius graph rebuilt every step",
+                       "candidates": B, "horizon": H * R, "particles": N_o + 1, "edges_per_graph": E,
+                       "parallelism": f"candidates sharded over {world} GPU(s), all-gather of costs",
+                       "ms_per_mpc_rollout": dt / args.steps * 1e3},
+            "roofline": {"bound": "mfma", "kernel": "k_edge_enc", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": int(n_edge),
+                         "flop_per_edge": FLOP_PER_EDGE, "edges_per_launch": edges_per_launch},
+            "kernel_ms_per_step": {f: v[0] / args.steps for f, v in fam_ms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cloud, task, Wt)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

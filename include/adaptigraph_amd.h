@@ -1,0 +1,152 @@
+/*
+ * adaptigraph_amd.h - C-ABI of the MI355X-native GNN-dynamics rollout engine.
+ *
+ * Drop-in boundary for ONE path of jhyau/AdaptiGraph: the GNN dynamics forward /
+ * rollout the MPC planner calls.  The reference has no FFI for this path - the
+ * boundary there is a Python callable (src/planning/real_world/planner.py:246,270
+ * -> src/planning/forward_dynamics.py:12).  This header is the C boundary placed
+ * UNDER that callable; adaptigraph_amd/ (Python, ctypes) keeps the reference's
+ * Python signatures on top of it.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - Every function returns 0 on success, a negative AG_ERR_* code otherwise;
+ *     ag_last_error(ctx) gives the message of the last failure on that ctx.
+ *   - Pointers named d_* are DEVICE pointers (e.g. torch tensor.data_ptr()),
+ *     h_* are host pointers.  All floating data is fp32, indices int32, masks
+ *     uint8 (0/1, the memory layout of a torch.bool tensor).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *     work is enqueued on it; no function synchronises the stream unless its
+ *     comment says so.
+ *   - The caller owns every input/output buffer.  The library owns only its
+ *     ctx workspace (grown monotonically, freed by ag_ctx_destroy).
+ *   - One ctx per (process, device); a ctx is not re-entrant.
+ *   - No float atomics anywhere: results are bit-reproducible and independent
+ *     of how candidates are chunked or sharded across GPUs.
+ */
+#ifndef ADAPTIGRAPH_AMD_H
+#define ADAPTIGRAPH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AG_OK 0
+#define AG_ERR_INVALID -1      /* bad argument (mirrors the reference's asserts, model.py:89,187,222,240,250) */
+#define AG_ERR_HIP -2          /* a HIP runtime call failed                                                  */
+#define AG_ERR_MAX_NR -3       /* a graph had more edges than max_nR: reference raises Exception("Exceeds max dims"),
+                                  src/dynamics/utils.py:63-65 via forward_dynamics.py:127-128,173-174          */
+#define AG_ERR_UNSUPPORTED -4  /* configuration outside what the kernels implement                            */
+#define AG_ERR_NO_WEIGHTS -5   /* forward/rollout before ag_ctx_load_weights                                   */
+
+#define AG_ABI_VERSION 1
+#define AG_NUM_WEIGHT_TENSORS 22
+
+typedef struct ag_ctx ag_ctx;
+
+/* Model dimensions = what DynamicsPredictor.__init__ derives from model_config
+ * (src/dynamics/gnn/model.py:78-123).  Every shipped config has nf=150, n_his=4,
+ * in_dim=6 (attr 2 + physics 1 + action 3), rel_dim=17 (2*attr 2 + group 1 + 3*n_his). */
+typedef struct ag_dims {
+    int32_t nf;            /* nf_particle == nf_relation == nf_effect; kernels are built for 150 */
+    int32_t n_his;         /* history frames; kernels are built for 4                            */
+    int32_t pstep;         /* message-passing rounds (3; softbody.yaml uses 4)                   */
+    int32_t in_dim;        /* particle-encoder input width, must be 6                            */
+    int32_t rel_dim;       /* relation-encoder input width, must be 17                           */
+    float motion_clamp;    /* model.py:86, 100.0                                                 */
+} ag_dims;
+
+/* Pusher/tool description for the rollout driver (forward_dynamics.py:40-81,163-168). */
+typedef struct ag_rollout_params {
+    int32_t B;             /* candidates                                                          */
+    int32_t H;             /* look-ahead steps (n_look_forward); 1 for the masked variant         */
+    int32_t N_o;           /* object particles (max_nobj)                                         */
+    int32_t M;             /* tool particles (eef_num)                                            */
+    int32_t topk;
+    int32_t connect_tools_all;
+    int32_t max_nR;        /* reference raises when a graph has more edges                        */
+    int32_t y_mode;        /* 0: tool y = min object y (dynamics, :40,:163); 1: masked mean (dynamics_masked, :235,:359) */
+    float adj_thresh;
+    float gripper_offset;  /* fp32(0.01*sim_real_ratio) if gripper_enable else 0 (:80-81,:167-168) */
+    int32_t gripper_enable;
+    float physics_param;   /* homogeneous physics parameter (forward_dynamics.py:151)             */
+} ag_rollout_params;
+
+uint32_t ag_abi_version(void);
+
+/* Create / destroy.  device_id is the HIP ordinal.  Does not touch the GPU beyond hipSetDevice + small mallocs. */
+int ag_ctx_create(int32_t device_id, const ag_dims* dims, ag_ctx** out_ctx);
+int ag_ctx_destroy(ag_ctx* ctx);
+const char* ag_last_error(const ag_ctx* ctx);
+
+/* Upload the 22 state_dict tensors of DynamicsPredictor (model.py:104-123), HOST pointers, torch layout
+ * (weight = (out,in) row-major), in this order:
+ *   0..5   particle_encoder.model.{0,2,4}.{weight,bias}      (150x6,150 | 150x150,150 | 150x150,150)
+ *   6..11  relation_encoder.model.{0,2,4}.{weight,bias}      (150x17,150 | 150x150,150 | 150x150,150)
+ *   12,13  particle_propagator.linear.{weight,bias}          (150x300,150)
+ *   14,15  relation_propagator.linear.{weight,bias}          (150x450,150)
+ *   16..21 non_rigid_predictor.linear_{0,1,2}.{weight,bias}  (150x150,150 | 150x150,150 | 3x150,3)
+ * Synchronous (repacks on the host, copies, waits). */
+int ag_ctx_load_weights(ag_ctx* ctx, const float* const* h_tensors, int32_t n_tensors);
+
+/* Tuning: candidates per launch wave of the rollout (0 = automatic). */
+int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
+
+/* Replaces construct_edges_from_states_batch (src/dynamics/dataset/graph.py:233-298).
+ *   d_pos (B,N,3); d_mask,d_tool_mask (B,N) uint8; adj_thresh scalar, or d_adj_thresh_vec (B,) if non-NULL.
+ * Outputs, per batch element b, in the reference's nonzero order (sorted by receiver, then sender):
+ *   d_recv,d_send (B,edge_cap) int32 (entries past n_edges[b] are left untouched),
+ *   d_row_ptr (B,N+1) int32 CSR offsets by receiver, d_n_edges (B,) int32 = TRUE edge count even when > edge_cap
+ *   (then nothing is written for that element).  The caller compares n_edges with its max_nR (pad_torch semantics). */
+int ag_build_edges(ag_ctx* ctx, void* stream, const float* d_pos, const uint8_t* d_mask, const uint8_t* d_tool_mask,
+                   int32_t B, int32_t N, float adj_thresh, const float* d_adj_thresh_vec, int32_t topk,
+                   int32_t connect_tools_all, int32_t edge_cap, int32_t* d_recv, int32_t* d_send,
+                   int32_t* d_row_ptr, int32_t* d_n_edges);
+
+/* Replaces DynamicsPredictor.forward (src/dynamics/gnn/model.py:130-342) on index-list graphs.
+ *   d_state (B,n_his,N,3); d_attrs (B,N,2); d_action (B,N,3); d_phys (B,N) physics parameter per particle, zero
+ *   for the trailing N-n_p tool particles (model.py:206-207); d_group (B,N,n_inst) = [p_instance ; 0] (model.py:264);
+ *   edges as produced by ag_build_edges (must be sorted by receiver; row_ptr consistent).
+ * Outputs d_pred_pos, d_pred_motion (B,n_p,3) (model.py:335-338). */
+int ag_forward(ag_ctx* ctx, void* stream, const float* d_state, const float* d_attrs, const float* d_action,
+               const float* d_phys, const float* d_group, int32_t n_inst, const int32_t* d_recv, const int32_t* d_send,
+               const int32_t* d_row_ptr, const int32_t* d_n_edges, int32_t edge_cap, int32_t B, int32_t N, int32_t n_p,
+               float* d_pred_pos, float* d_pred_motion);
+
+/* Replaces the device side of dynamics() / dynamics_masked() (src/planning/forward_dynamics.py:12-205, 209-399):
+ * the whole look-ahead x action-repeat loop, graph rebuilt every step, no host sync inside.
+ *   d_state0      y_mode 0: (N_o,3) one start cloud broadcast to all candidates (:25);
+ *                 y_mode 1: (B,N_o,3) per-candidate padded clouds (:225-227)
+ *   d_obj_mask    (B,N_o) uint8 or NULL (= all valid)                                   (:107-115 / :302-309)
+ *   d_eef_xz      (B,H,M,2) tool start x,z per look-ahead step; d_eef_delta (B,H,M,3)   (:42-75, computed by the shim
+ *                 with torch CPU ops exactly as the reference does, so cos/sin bits match)
+ *   h_repeat      (B,H) int32 HOST array = action_repeat (plan_utils.py:16)
+ *   d_phys_vec    NULL (use p->physics_param for every object particle), or (N_o,) per-particle physics parameters
+ *                 shared by all candidates (the (B,n_p) branch of model.py:200-204 fed by forward_dynamics.py:151)
+ *   d_state_seqs  (B,H,N_o,3) output, fully written (zeros where repeat==0, :32)
+ * Synchronises the stream once at the end to read the overflow flag; returns AG_ERR_MAX_NR if any consumed graph
+ * had more than max_nR edges (the shim re-raises Exception("Exceeds max dims")). */
+int ag_rollout(ag_ctx* ctx, void* stream, const ag_rollout_params* p, const float* d_state0, const uint8_t* d_obj_mask,
+               const float* d_eef_xz, const float* d_eef_delta, const int32_t* h_repeat, const float* d_phys_vec,
+               float* d_state_seqs);
+
+/* Same, but never synchronises: enqueue only.  *d_overflow_flag (int32, device, caller-zeroed) receives the max
+ * edge count seen if it exceeded max_nR.  Used by bench.py to time the pure device path. */
+int ag_rollout_async(ag_ctx* ctx, void* stream, const ag_rollout_params* p, const float* d_state0,
+                     const uint8_t* d_obj_mask, const float* d_eef_xz, const float* d_eef_delta,
+                     const int32_t* h_repeat, const float* d_phys_vec, float* d_state_seqs,
+                     int32_t* d_overflow_flag);
+
+/* Introspection for bench.py / tests: HIP-event time of every launch of a kernel family, recorded on the stream the
+ * kernels run on.  family_mask bit i enables family i of: edge_count, edge_emit, prep, node_enc, edge_enc, mp,
+ * node_prop, node_final, roll_init, roll_update (0 = off, -1 = all).  ag_ctx_kernel_stats waits for the recorded
+ * events and returns the total milliseconds and launch count since the last reset. */
+int ag_ctx_set_profiling(ag_ctx* ctx, int32_t family_mask);
+int ag_ctx_kernel_stats(ag_ctx* ctx, const char* kernel, double* out_total_ms, int64_t* out_launches);
+int ag_ctx_reset_stats(ag_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAPTIGRAPH_AMD_H */
