@@ -207,8 +207,10 @@ int pick_slices(int B, int N) {
 int auto_chunk(const ag_ctx* c, int B, int N) {
     if (c->chunk > 0) return std::min(c->chunk, B);
     if (const char* e = getenv("AG_CHUNK")) { int v = atoi(e); if (v > 0) return std::min(v, B); }
-    const long target_rows = 131072;   // >= 2 full waves of 256-row workgroups on 256 CUs for the node chains
-    long bc = (target_rows + N - 1) / N;
+    // Node chains run one 256-row workgroup per CU: pick the largest chunk whose workgroup count is <= 2 x 256 CUs,
+    // so the grid is two (nearly) full rounds and never spills a few workgroups into a third.
+    const long max_rows = 2L * 256 * 256;
+    long bc = max_rows / N;
     return (int)std::max(1L, std::min<long>(bc, B));
 }
 
