@@ -13,6 +13,7 @@
 
 namespace ag {
 size_t edge_build_max_particles();
+int edge_ell_stride(int N, int topk);
 }
 using namespace ag;
 
@@ -137,7 +138,7 @@ void pack_first(float* dst, const float* W, int in_dim, const float* bias, int n
 struct Work {
     GraphBufs g{};
     RollBufs r{};
-    unsigned long long* tstar; int* deg; int* slice_tot; int* cta_flag;
+    int* ell; int* deg; int* slice_tot; int* cta_flag;
     int* recv; int* send; int* row_ptr; int* n_edges;
 };
 
@@ -155,12 +156,12 @@ int ensure_slab(ag_ctx* c, size_t bytes) {
 
 // carve a workspace for Bc candidates.  own_edges: allocate edge index arrays + builder scratch; roll: rollout state
 int make_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices, bool own_edges,
-              bool roll, bool own_group, int N_o) {
+              bool roll, bool own_group, int N_o, int ell_stride) {
     const size_t rows = (size_t)Bc * N;
     size_t bytes = 0;
     bytes += 16 * 256;
     bytes += rows * (NODE_IN + F12 + (own_group ? n_inst : 0)) * 4 + 5 * rows * NFP * 4 + (size_t)Bc * c_cap * NFP * 4;
-    if (own_edges) bytes += rows * 12 + (size_t)Bc * (slices + 2) * 4 + 2 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
+    if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 2) * 4 + 2 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
     if (roll) bytes += (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows;
     bytes += 64 * 256;
     int rc = ensure_slab(c, bytes);
@@ -177,7 +178,7 @@ int make_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int c
     w.g.C = s.take<float>((size_t)Bc * c_cap * NFP);
     w.g.B = Bc; w.g.N = N; w.g.n_inst = n_inst; w.g.edge_cap = edge_cap; w.g.c_cap = c_cap; w.g.n_p = N_o;
     if (own_edges) {
-        w.tstar = s.take<unsigned long long>(rows);
+        w.ell = s.take<int>(rows * (size_t)std::max(1, ell_stride));
         w.deg = s.take<int>(rows);
         w.slice_tot = s.take<int>((size_t)Bc * slices);
         w.cta_flag = s.take<int>(Bc);
@@ -319,12 +320,13 @@ int ag_build_edges(ag_ctx* c, void* stream, const float* d_pos, const uint8_t* d
     HIPCHK(c, hipSetDevice(c->device));
     const int slices = pick_slices(B, N);
     const size_t rows = (size_t)B * N;
-    rc = ensure_slab(c, rows * 12 + (size_t)B * (slices + 1) * 4 + 4096);
+    const int ell_stride = edge_ell_stride(N, topk);
+    rc = ensure_slab(c, rows * (size_t)(ell_stride + 1) * 4 + (size_t)B * (slices + 1) * 4 + 4096);
     if (rc) return rc;
     EdgeArgs a{};
     a.pos = d_pos; a.pos_bstride = (long)N * 3; a.mask = d_mask; a.tool = d_tool; a.thr_vec = d_thr_vec; a.thr = thr;
     a.B = B; a.N = N; a.topk = topk; a.cta = cta ? 1 : 0; a.edge_cap = edge_cap; a.slices = slices;
-    a.tstar = c->slab.take<unsigned long long>(rows);
+    a.ell = c->slab.take<int>(rows * (size_t)std::max(1, ell_stride));
     a.deg = c->slab.take<int>(rows);
     a.slice_tot = c->slab.take<int>((size_t)B * slices);
     a.cta_flag = c->slab.take<int>(B);
@@ -352,7 +354,7 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
     const int Bc = auto_chunk(c, B, N);
     const int c_cap = (int)round_up(edge_cap, 256);
     Work w{};
-    int rc = make_work(c, w, Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p);
+    int rc = make_work(c, w, Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0);
     if (rc) return rc;
     for (int b0 = 0; b0 < B; b0 += Bc) {
         const int nb = std::min(Bc, B - b0);
@@ -406,7 +408,7 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     const int Bc = auto_chunk(c, p->B, N);
     const int slices = pick_slices(Bc, N);
     Work w{};
-    rc = make_work(c, w, Bc, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o);
+    rc = make_work(c, w, Bc, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, edge_ell_stride(N, p->topk));
     if (rc) return rc;
 
     for (int b0 = 0; b0 < p->B; b0 += Bc) {
@@ -422,7 +424,7 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         ea.pos = w.r.hist + (size_t)(N_HIS - 1) * N * 3; ea.pos_bstride = (long)N_HIS * N * 3;
         ea.mask = w.r.mask; ea.tool = w.r.tool; ea.thr_vec = nullptr; ea.thr = p->adj_thresh;
         ea.B = nb; ea.N = N; ea.topk = p->topk; ea.cta = p->connect_tools_all ? 1 : 0; ea.edge_cap = edge_cap;
-        ea.slices = slices; ea.tstar = w.tstar; ea.deg = w.deg; ea.slice_tot = w.slice_tot; ea.cta_flag = w.cta_flag;
+        ea.slices = slices; ea.ell = w.ell; ea.deg = w.deg; ea.slice_tot = w.slice_tot; ea.cta_flag = w.cta_flag;
         ea.recv = w.recv; ea.send = w.send; ea.row_ptr = w.row_ptr; ea.n_edges = w.n_edges;
         ea.overflow = d_overflow_flag; ea.max_nR = p->max_nR; ea.zero_on_overflow = 1;
         for (int li = 0; li < p->H; ++li) {

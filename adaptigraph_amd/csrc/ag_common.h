@@ -68,7 +68,7 @@ struct EdgeArgs {
     const float* thr_vec;       // (B,) or null
     float thr;
     int B, N, topk, cta, edge_cap, slices;
-    unsigned long long* tstar;  // (B,N) scratch: per-row k-th smallest key
+    int* ell;                   // (B,N,min(topk,N)) scratch: kept senders per row (unused when topk >= N)
     int* deg;                   // (B,N) scratch
     int* slice_tot;             // (B,slices) scratch
     int* cta_flag;              // (B,) scratch: connect_tools_all batch flag

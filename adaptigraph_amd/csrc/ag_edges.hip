@@ -15,9 +15,21 @@
 //     connect_tools_all rules                                                            graph.py:276-286
 //     edge order = row-major nonzero = sorted by (receiver, sender)                      graph.py:293
 //
+// Work avoidance that cannot change the result:
+//   * senders are taken in chunks of 64 consecutive indices; each chunk has an axis-aligned bounding box of its
+//     valid particles.  A chunk is skipped for receiver i when fl(x_i - max_x) >= thr (or the mirrored / y / z
+//     tests): rounding is monotonic, so every sender j of the chunk has |fl(x_i - x_j)| >= thr, hence
+//     fl(dx*dx) >= fl(thr*thr) = thr2 and dis >= thr2 - exactly the pairs the reference's test rejects.  One
+//     lane tests one chunk, a ballot gives the survivor mask.  (Pays off when consecutive particle indices are
+//     spatially coherent, e.g. grids and ropes; costs ~one sweep otherwise.)
+//   * with top-k active, the in-radius candidates of a row are collected once into an LDS buffer; the k-th
+//     smallest (dis, j) key is found by rank counting; the kept senders go to a per-row ELL scratch (<= k
+//     entries) and the emit kernel is a scan plus a merge-copy (tool senders of connect_tools_all are merged in
+//     index order).  Without top-k (topk >= N) rows are unbounded, so the emit kernel sweeps again.
+//
 // Two kernels, no inter-workgroup communication inside a launch:
-//   k_edge_count : per row the k-th smallest key T* (selection in an LDS candidate buffer) and the row degree
-//   k_edge_emit  : scan of degrees -> row_ptr, then a second sweep that writes (recv, send) in order
+//   k_edge_count : per-row kept list (ELL) + degree, slice totals, connect_tools_all flag
+//   k_edge_emit  : scan of degrees -> row_ptr, then writes (recv, send) in order
 #include "ag_common.h"
 
 namespace ag {
@@ -25,13 +37,15 @@ namespace ag {
 constexpr int EW = 1024;          // threads per workgroup (16 wavefronts)
 constexpr int EWAVES = EW / 64;
 constexpr int CAP = 256;          // candidate-buffer entries per wavefront
+constexpr int MAXCH = 64;         // sender chunks per candidate (N <= 4096)
 constexpr unsigned long long KEY_INF = ~0ull;
 
 struct EdgeDev {
     const float* pos; long pos_bstride;  // floats between candidates
     const uint8_t* mask; const uint8_t* tool; const float* thr_vec; float thr;
     int B, N, k, topk_active, cta, edge_cap, slices, rows_per_slice;
-    unsigned long long* tstar; int* deg; int* slice_tot; int* cta_flag;
+    int* ell;                            // (B, N, k) kept non-merged senders per row (top-k active only)
+    int* deg; int* slice_tot; int* cta_flag;
     int* recv; int* send; int* row_ptr; int* n_edges; int* overflow; int max_nR; int zero_on_overflow;
 };
 
@@ -39,59 +53,125 @@ __device__ __forceinline__ float dist_exact(float xi, float yi, float zi, float 
     const float dx = __fsub_rn(xi, xj), dy = __fsub_rn(yi, yj), dz = __fsub_rn(zi, zj);
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
-
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+__device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
-// LDS carve: x[N] y[N] z[N] floats | keys[EWAVES][CAP] u64 | flags[N] bytes | scan ints
+// LDS carve.  The 32 KB candidate-key area of k_edge_count is reused by k_edge_emit for its scan / tool tables.
 struct EdgeLds {
-    float* x; float* y; float* z; unsigned long long* keys; uint8_t* fl; int* misc;
+    unsigned long long* keys;   // [EWAVES][CAP]                                   (count kernel)
+    int* scan;                  // [EW]                                            (emit kernel, overlays keys)
+    unsigned short* tprefix;    // [Np+4] number of tools with index < j           (emit kernel, overlays keys)
+    unsigned short* tlist;      // [Np]   tool indices in ascending order          (emit kernel, overlays keys)
+    float* x; float* y; float* z;
+    float* bb;                  // [6][MAXCH] chunk boxes: minx maxx miny maxy minz maxz
+    int* misc;                  // [64]  0: cta flag, 1: slice total, 2: tool count
+    uint8_t* fl;                // [Np] bit0 valid, bit1 tool
 };
+static_assert(EW * 4 + 2 * (MAXCH * 64 + 4) * 2 <= EWAVES * CAP * 8, "emit tables must fit in the key area");
+__host__ __device__ inline size_t edge_lds_bytes(int N) {
+    const size_t Np = (size_t)((N + 3) & ~3);
+    return (size_t)EWAVES * CAP * 8 + Np * 12 + 6 * MAXCH * 4 + 64 * 4 + Np + 16;
+}
 __device__ __forceinline__ EdgeLds carve(unsigned char* base, int N) {
     EdgeLds l;
     const int Np = (N + 3) & ~3;
     l.keys = reinterpret_cast<unsigned long long*>(base);
+    l.scan = reinterpret_cast<int*>(base);
+    l.tprefix = reinterpret_cast<unsigned short*>(base + EW * 4);
+    l.tlist = l.tprefix + Np + 4;
     l.x = reinterpret_cast<float*>(base + (size_t)EWAVES * CAP * 8);
     l.y = l.x + Np;
     l.z = l.y + Np;
-    l.misc = reinterpret_cast<int*>(l.z + Np);       // 64 ints
+    l.bb = l.z + Np;
+    l.misc = reinterpret_cast<int*>(l.bb + 6 * MAXCH);
     l.fl = reinterpret_cast<uint8_t*>(l.misc + 64);
     return l;
 }
-static size_t edge_lds_bytes(int N) {
-    const int Np = (N + 3) & ~3;
-    return (size_t)EWAVES * CAP * 8 + (size_t)Np * 12 + 64 * 4 + (size_t)Np + 16;
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
 }
 
-__device__ __forceinline__ void load_candidate(const EdgeDev& a, const EdgeLds& l, int b) {
+// positions + flags -> LDS, chunk boxes, tool count.  Ends with a barrier.
+__device__ void load_candidate(const EdgeDev& a, const EdgeLds& l, int b, bool want_pos) {
     const float* p = a.pos + (long)b * a.pos_bstride;
+    if (threadIdx.x < 64) l.misc[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < a.N; i += EW) {
-        l.x[i] = p[3 * i + 0];
-        l.y[i] = p[3 * i + 1];
-        l.z[i] = p[3 * i + 2];
+        if (want_pos) {
+            l.x[i] = p[3 * i + 0];
+            l.y[i] = p[3 * i + 1];
+            l.z[i] = p[3 * i + 2];
+        }
         l.fl[i] = (a.mask[(long)b * a.N + i] ? 1 : 0) | (a.tool[(long)b * a.N + i] ? 2 : 0);
     }
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int nch = (a.N + 63) >> 6;
+    int ntool = 0;
+    for (int c = wave; c < nch; c += EWAVES) {
+        const int j = 64 * c + lane;
+        const bool inb = j < a.N;
+        const int f = inb ? l.fl[j] : 0;
+        ntool += __popcll(__ballot(inb && (f & 2)));
+        if (want_pos) {
+            const bool v = inb && (f & 1);
+            const float INF = __builtin_huge_valf();
+            const float xj = v ? l.x[j] : 0.f, yj = v ? l.y[j] : 0.f, zj = v ? l.z[j] : 0.f;
+            const float mnx = wave_min(v ? xj : INF), mxx = wave_max(v ? xj : -INF);
+            const float mny = wave_min(v ? yj : INF), mxy = wave_max(v ? yj : -INF);
+            const float mnz = wave_min(v ? zj : INF), mxz = wave_max(v ? zj : -INF);
+            if (lane == 0) {
+                l.bb[0 * MAXCH + c] = mnx; l.bb[1 * MAXCH + c] = mxx; l.bb[2 * MAXCH + c] = mny;
+                l.bb[3 * MAXCH + c] = mxy; l.bb[4 * MAXCH + c] = mnz; l.bb[5 * MAXCH + c] = mxz;
+            }
+        }
+    }
+    if (lane == 0 && ntool) atomicAdd(&l.misc[2], ntool);
+    __syncthreads();
 }
 
-// distance key of pair (i, j) for lane's sender j; returns `within` and the 64-bit (dis, j) key
-__device__ __forceinline__ bool pair_key(const EdgeLds& l, int N, float xi, float yi, float zi, int fi, int j, float thr2,
-                                         unsigned long long& key, int& fj) {
+// chunks that can contain a sender within the radius of (xi,yi,zi): bit c set = must sweep chunk c
+__device__ __forceinline__ unsigned long long survivors(const EdgeLds& l, int N, float xi, float yi, float zi, float thr) {
+    thr = fabsf(thr);                                      // thr enters the adjacency test only as thr*thr
+    const int lane = lane_id();
+    const int nch = (N + 63) >> 6;
+    bool keep = false;
+    if (lane < nch) {
+        const float mnx = l.bb[0 * MAXCH + lane], mxx = l.bb[1 * MAXCH + lane];
+        const float mny = l.bb[2 * MAXCH + lane], mxy = l.bb[3 * MAXCH + lane];
+        const float mnz = l.bb[4 * MAXCH + lane], mxz = l.bb[5 * MAXCH + lane];
+        // exact rejection (see header): every |fl(c_i - c_j)| >= thr.  Empty chunks have min=+inf, max=-inf.
+        const bool out = (__fsub_rn(xi, mxx) >= thr) || (__fsub_rn(mnx, xi) >= thr) ||
+                         (__fsub_rn(yi, mxy) >= thr) || (__fsub_rn(mny, yi) >= thr) ||
+                         (__fsub_rn(zi, mxz) >= thr) || (__fsub_rn(mnz, zi) >= thr);
+        keep = !out;
+    }
+    return __ballot(keep);
+}
+
+// lane's sender j against receiver i: distance with the reference's masking; returns `within`
+__device__ __forceinline__ bool pair_within(const EdgeLds& l, int N, float xi, float yi, float zi, int fi, int j,
+                                            float thr2, float& d, int& fj) {
     const bool vj = j < N;
     const int jj = vj ? j : 0;
     fj = l.fl[jj];
-    float d = dist_exact(xi, yi, zi, l.x[jj], l.y[jj], l.z[jj]);
-    if (!((fi & 1) && (fj & 1))) d = 1e10f;          // graph.py:253-256
-    if ((fi & 2) && (fj & 2)) d = 1e10f;             // graph.py:257-260
-    key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)jj;
-    return vj && (__fsub_rn(d, thr2) < 0.0f);        // graph.py:267
+    d = dist_exact(xi, yi, zi, l.x[jj], l.y[jj], l.z[jj]);
+    if (!(fj & 1) || ((fi & 2) && (fj & 2))) d = 1e10f;    // graph.py:253-260 (receiver validity handled by caller)
+    return vj && (__fsub_rn(d, thr2) < 0.0f);              // graph.py:267
 }
 
-// k-th smallest key among keys[0..nb) of this wavefront (nb <= CAP); optionally compacts the k smallest to the
-// front in sorted order.  Keys are distinct (the sender index is in the low word).
+// rank counting over keys[0..nb): returns the k-th smallest key; optionally compacts the k smallest to the front.
 __device__ __forceinline__ unsigned long long select_kth(unsigned long long* keys, int nb, int k, bool compact) {
     const int lane = lane_id();
     unsigned long long mine[CAP / 64];
@@ -103,7 +183,7 @@ __device__ __forceinline__ unsigned long long select_kth(unsigned long long* key
         rank[u] = 0;
     }
     for (int t = 0; t < nb; ++t) {
-        const unsigned long long other = keys[t];    // same address in every lane: LDS broadcast
+        const unsigned long long other = keys[t];          // same address in every lane: LDS broadcast
 #pragma unroll
         for (int u = 0; u < CAP / 64; ++u) rank[u] += other < mine[u] ? 1 : 0;
     }
@@ -126,147 +206,201 @@ __device__ __forceinline__ unsigned long long select_kth(unsigned long long* key
     return kth;
 }
 
-// Pass A for receiver row i: T* = k-th smallest (dis, j) key among in-radius senders, or KEY_INF when the top-k
-// constraint does not bind (k >= N, or at most k senders in radius).
-__device__ unsigned long long row_tstar(const EdgeDev& a, const EdgeLds& l, int i, float thr2) {
-    if (!a.topk_active) return KEY_INF;
+// One receiver row, top-k active.  Collects in-radius senders, applies top-k, writes the kept senders that are not
+// governed by the connect_tools_all rule to ell_row (ascending sender index) and returns their count.
+// *nontool_raw receives the number of kept NON-tool senders before the tool-receiver rule (feeds graph.py:277).
+__device__ int row_topk(const EdgeDev& a, const EdgeLds& l, int i, float thr, float thr2, int* ell_row, int* nontool_raw) {
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
-    unsigned long long* keys = l.keys + wave * CAP;
+    unsigned long long* keys = l.keys + (threadIdx.x >> 6) * CAP;
     const float xi = l.x[i], yi = l.y[i], zi = l.z[i];
     const int fi = l.fl[i];
+    *nontool_raw = 0;
+    if (!(fi & 1)) return 0;                               // invalid receiver: every pair is masked (graph.py:256)
     int cnt = 0, nb = 0;
+    bool reordered = false;
     unsigned long long T = KEY_INF;
-    for (int c0 = 0; c0 < a.N; c0 += 64) {
-        unsigned long long key; int fj;
-        const bool within = pair_key(l, a.N, xi, yi, zi, fi, c0 + lane, thr2, key, fj);
+    unsigned long long todo = survivors(l, a.N, xi, yi, zi, thr);
+    while (todo) {
+        const int c = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        float d; int fj;
+        const int j = 64 * c + lane;
+        const bool within = pair_within(l, a.N, xi, yi, zi, fi, j, thr2, d, fj);
         const unsigned long long bw = __ballot(within);
+        if (!bw) continue;
         cnt += __popcll(bw);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j;
         const bool push = within && key < T;
         const unsigned long long bp = __ballot(push);
         if (bp) {
-            const int pos = nb + __popcll(bp & ((1ull << lane) - 1ull));
-            if (push) keys[pos] = key;
+            if (push) keys[nb + __popcll(bp & lanes_below(lane))] = key;
             nb += __popcll(bp);
             wave_lds_sync();
-            if (nb > CAP - 64) {                     // keep only the k smallest so far; tighten T
+            if (nb > CAP - 64) {                           // keep only the k smallest so far; tighten T
                 T = select_kth(keys, nb, a.k, true);
                 nb = a.k;
+                reordered = true;
             }
         }
     }
-    if (cnt <= a.k) return KEY_INF;
-    return select_kth(keys, nb, a.k, false);
+    const unsigned long long tstar = cnt > a.k ? select_kth(keys, nb, a.k, false) : KEY_INF;
+    // kept = key <= tstar.  Rank the kept entries by sender index (the buffer is already ascending unless a
+    // compaction reordered it) and write them out.
+    int total = 0, raw = 0;
+    if (!reordered) {
+        for (int e0 = 0; e0 < nb; e0 += 64) {
+            const int e = e0 + lane;
+            const unsigned long long key = e < nb ? keys[e] : KEY_INF;
+            const int j = (int)(key & 0xffffffffull);
+            const bool kept = e < nb && key <= tstar;
+            const bool jt = kept && (l.fl[j] & 2);
+            raw += __popcll(__ballot(kept && !jt));
+            const bool out = kept && (!a.cta || (!jt && !(fi & 2)));   // graph.py:283-286 handled at emit
+            const unsigned long long bo = __ballot(out);
+            if (out) ell_row[total + __popcll(bo & lanes_below(lane))] = j;
+            total += __popcll(bo);
+        }
+    } else {
+        unsigned mine[CAP / 64]; bool outm[CAP / 64]; int pos[CAP / 64];
+#pragma unroll
+        for (int u = 0; u < CAP / 64; ++u) {
+            const int e = lane + 64 * u;
+            const unsigned long long key = e < nb ? keys[e] : KEY_INF;
+            mine[u] = (unsigned)(key & 0xffffffffull);
+            const bool kept = e < nb && key <= tstar;
+            const bool jt = kept && (l.fl[mine[u]] & 2);
+            raw += __popcll(__ballot(kept && !jt));
+            outm[u] = kept && (!a.cta || (!jt && !(fi & 2)));
+            pos[u] = 0;
+        }
+        for (int t = 0; t < nb; ++t) {
+            const unsigned long long ko = keys[t];
+            const unsigned jo = (unsigned)(ko & 0xffffffffull);
+            const bool oo = ko <= tstar && (!a.cta || (!(l.fl[jo] & 2) && !(fi & 2)));
+#pragma unroll
+            for (int u = 0; u < CAP / 64; ++u) pos[u] += (oo && jo < mine[u]) ? 1 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < CAP / 64; ++u) {
+            if (outm[u]) ell_row[pos[u]] = (int)mine[u];
+            total += __popcll(__ballot(outm[u]));
+        }
+    }
+    *nontool_raw = raw;
+    return total;
 }
 
-// membership of sender j (this lane) in the final adjacency row i
-__device__ __forceinline__ bool member(const EdgeDev& a, const EdgeLds& l, int i, int j, float xi, float yi, float zi,
-                                       int fi, float thr2, unsigned long long tstar, int flag) {
-    unsigned long long key; int fj;
-    const bool within = pair_key(l, a.N, xi, yi, zi, fi, j, thr2, key, fj);
-    const bool kept = within && key <= tstar;        // radius AND top-k      graph.py:267-274
-    if (!a.cta) return kept;
+// membership of sender j (this lane) in the final adjacency row i when top-k is NOT active
+__device__ __forceinline__ bool member_radius(const EdgeDev& a, const EdgeLds& l, int i, int j, float xi, float yi,
+                                              float zi, int fi, float thr2, int flag) {
+    float d; int fj;
+    const bool within = (fi & 1) && pair_within(l, a.N, xi, yi, zi, fi, j, thr2, d, fj);
+    if (!a.cta) return within;
     if (j >= a.N) return false;
-    if (fj & 2) return (fi & 1) && flag;             // tool sender, valid receiver: all-or-nothing  graph.py:284,286
-    return kept && !(fi & 2);                        // tool receiver loses its object senders        graph.py:283,285
+    if (fj & 2) return (fi & 1) && flag;                   // graph.py:284,286
+    return within && !(fi & 2);                            // graph.py:283,285
 }
 
-// connect_tools_all batch flag: does any tool receiver keep a non-tool sender after radius AND top-k?  graph.py:277
-__device__ void compute_cta_flag(const EdgeDev& a, const EdgeLds& l, float thr2) {
+__device__ __forceinline__ float thr_of(const EdgeDev& a, int b) { return a.thr_vec ? a.thr_vec[b] : a.thr; }
+
+// number of final senders of row i when top-k is not active (full sweep with culling); nontool_raw as above
+__device__ int row_radius_count(const EdgeDev& a, const EdgeLds& l, int i, float thr, float thr2, int flag, int* nontool_raw) {
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) l.misc[0] = 0;
-    __syncthreads();
-    if (a.cta) {
-        for (int i = wave; i < a.N; i += EWAVES) {
-            if (!(l.fl[i] & 2)) continue;            // wave-uniform
-            const unsigned long long ts = row_tstar(a, l, i, thr2);
-            const float xi = l.x[i], yi = l.y[i], zi = l.z[i];
-            const int fi = l.fl[i];
-            bool any = false;
-            for (int c0 = 0; c0 < a.N; c0 += 64) {
-                unsigned long long key; int fj;
-                const bool within = pair_key(l, a.N, xi, yi, zi, fi, c0 + lane, thr2, key, fj);
-                any |= within && key <= ts && !(fj & 2);
-            }
-            if (__ballot(any) && lane == 0) atomicOr(&l.misc[0], 1);
+    const float xi = l.x[i], yi = l.y[i], zi = l.z[i];
+    const int fi = l.fl[i];
+    int n = 0, raw = 0;
+    if (fi & 1) {
+        unsigned long long todo = survivors(l, a.N, xi, yi, zi, thr);
+        while (todo) {
+            const int c = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            float d; int fj;
+            const bool within = pair_within(l, a.N, xi, yi, zi, fi, 64 * c + lane, thr2, d, fj);
+            raw += __popcll(__ballot(within && !(fj & 2)));
+            n += __popcll(__ballot(within && (!a.cta || (!(fj & 2) && !(fi & 2)))));
         }
     }
-    __syncthreads();
-}
-
-__device__ __forceinline__ float thr2_of(const EdgeDev& a, int b) {
-    const float t = a.thr_vec ? a.thr_vec[b] : a.thr;
-    return __fmul_rn(t, t);                          // graph.py:250 fp32 * fp32
+    *nontool_raw = raw;
+    return n;
 }
 
 __global__ __launch_bounds__(EW) void k_edge_count(EdgeDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / a.slices, sl = blockIdx.x % a.slices;
     const EdgeLds l = carve(smem, a.N);
-    load_candidate(a, l, b);
-    __syncthreads();
-    const float thr2 = thr2_of(a, b);
-    compute_cta_flag(a, l, thr2);
-    const int flag = l.misc[0];
-    if (threadIdx.x == 0) { l.misc[1] = 0; if (sl == 0) a.cta_flag[b] = flag; }
-    __syncthreads();
+    load_candidate(a, l, b, true);
+    const float thr = thr_of(a, b);
+    const float thr2 = __fmul_rn(thr, thr);                // graph.py:250 fp32 * fp32
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int r0 = sl * a.rows_per_slice;
     const int r1 = min(a.N, r0 + a.rows_per_slice);
-    int my_tot = 0;
-    for (int i = r0 + wave; i < r1; i += EWAVES) {
-        const unsigned long long ts = row_tstar(a, l, i, thr2);
-        const float xi = l.x[i], yi = l.y[i], zi = l.z[i];
-        const int fi = l.fl[i];
-        int d = 0;
-        for (int c0 = 0; c0 < a.N; c0 += 64)
-            d += __popcll(__ballot(member(a, l, i, c0 + lane, xi, yi, zi, fi, thr2, ts, flag)));
+    const int ntool = l.misc[2];
+    // pass 1: rows of this slice (+ every tool row, whose non-tool senders decide the batch flag graph.py:277)
+    for (int i = wave; i < a.N; i += EWAVES) {
+        const bool mine = i >= r0 && i < r1;
+        const bool is_tool = l.fl[i] & 2;
+        if (!mine && !(a.cta && is_tool)) continue;        // wave-uniform
+        int raw = 0, n;
+        if (a.topk_active) n = row_topk(a, l, i, thr, thr2, a.ell + ((long)b * a.N + i) * a.k, &raw);
+        else n = row_radius_count(a, l, i, thr, thr2, 0, &raw);
         if (lane == 0) {
-            a.tstar[(long)b * a.N + i] = ts;
-            a.deg[(long)b * a.N + i] = d;
+            if (mine) a.deg[(long)b * a.N + i] = n;        // senders not governed by the tool rule
+            if (a.cta && is_tool && raw) atomicOr(&l.misc[0], 1);
         }
-        my_tot += d;
     }
-    if (lane == 0 && my_tot) atomicAdd(&l.misc[1], my_tot);   // integer add: order-independent
     __syncthreads();
-    if (threadIdx.x == 0) a.slice_tot[b * a.slices + sl] = l.misc[1];
+    const int flag = l.misc[0];
+    // pass 2: add the all-or-nothing tool senders (graph.py:284,286) and total the slice
+    int my = 0;
+    for (int i = r0 + threadIdx.x; i < r1; i += EW) {
+        int d = a.deg[(long)b * a.N + i];
+        if (a.cta && (l.fl[i] & 1) && flag) d += ntool;
+        a.deg[(long)b * a.N + i] = d;
+        my += d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) my += __shfl_xor(my, o);
+    if (lane == 0 && my) atomicAdd(&l.misc[1], my);        // integer add: order-independent
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.slice_tot[b * a.slices + sl] = l.misc[1];
+        if (sl == 0) a.cta_flag[b] = flag;
+    }
 }
 
 __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / a.slices, sl = blockIdx.x % a.slices;
     const EdgeLds l = carve(smem, a.N);
-    load_candidate(a, l, b);
+    load_candidate(a, l, b, !a.topk_active);
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int r0 = sl * a.rows_per_slice;
     const int r1 = min(a.N, r0 + a.rows_per_slice);
     const int nrows = max(0, r1 - r0);
-    // keys area is reused as the int scan buffer for this slice's degrees (nrows <= N ints <= 16*256*2 ints? no:
-    // only 8192 ints fit, so scan in registers per thread and keep per-thread bases in LDS instead)
-    int* tbase = reinterpret_cast<int*>(l.keys);     // EW ints
+    const int flag = a.cta_flag[b];
+    const int ntool = l.misc[2];
+    const bool tools_on = a.cta && flag && ntool > 0;
     int base = 0, total = 0;
     for (int s = 0; s < a.slices; ++s) {
         const int v = a.slice_tot[b * a.slices + s];
         if (s < sl) base += v;
         total += v;
     }
-    // each thread owns a contiguous run of rows of the slice
+    // ---- exclusive scan of this slice's degrees: each thread owns a contiguous run of rows
     const int per = (nrows + EW - 1) / EW;
     const int t0 = min(nrows, (int)threadIdx.x * per), t1 = min(nrows, t0 + per);
     int mysum = 0;
     for (int t = t0; t < t1; ++t) mysum += a.deg[(long)b * a.N + r0 + t];
-    tbase[threadIdx.x] = mysum;
+    l.scan[threadIdx.x] = mysum;
     __syncthreads();
-    // exclusive scan over EW partial sums (Hillis-Steele in LDS, integers)
-    for (int off = 1; off < EW; off <<= 1) {
+    for (int off = 1; off < EW; off <<= 1) {               // Hillis-Steele, integers
         int v = 0;
-        if ((int)threadIdx.x >= off) v = tbase[threadIdx.x - off];
+        if ((int)threadIdx.x >= off) v = l.scan[threadIdx.x - off];
         __syncthreads();
-        tbase[threadIdx.x] += v;
+        l.scan[threadIdx.x] += v;
         __syncthreads();
     }
-    int run = base + tbase[threadIdx.x] - mysum;
+    int run = base + l.scan[threadIdx.x] - mysum;
     const bool fits = total <= a.edge_cap;
     const bool hide = !fits && a.zero_on_overflow;          // downstream kernels then see an empty graph
     for (int t = t0; t < t1; ++t) {
@@ -278,24 +412,75 @@ __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
         a.n_edges[b] = hide ? 0 : total;
         if (a.overflow && total > a.max_nR) atomicMax(a.overflow, total);
     }
-    __syncthreads();   // row_ptr of this slice is complete and visible inside the workgroup
+    // ---- tool index tables for the merge (tprefix[j] = tools with index < j; tlist ascending)
+    if (tools_on) {
+        __syncthreads();
+        const int perN = (a.N + EW - 1) / EW;
+        const int j0 = min(a.N, (int)threadIdx.x * perN), j1 = min(a.N, j0 + perN);
+        int c = 0;
+        for (int j = j0; j < j1; ++j) c += (l.fl[j] & 2) ? 1 : 0;
+        l.scan[threadIdx.x] = c;
+        __syncthreads();
+        for (int off = 1; off < EW; off <<= 1) {
+            int v = 0;
+            if ((int)threadIdx.x >= off) v = l.scan[threadIdx.x - off];
+            __syncthreads();
+            l.scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        int r = l.scan[threadIdx.x] - c;
+        for (int j = j0; j < j1; ++j) {
+            l.tprefix[j] = (unsigned short)r;
+            if (l.fl[j] & 2) { l.tlist[r] = (unsigned short)j; ++r; }
+        }
+    }
+    __syncthreads();   // row_ptr of this slice and the tool tables are complete and visible inside the workgroup
     if (!fits) return;
-    const float thr2 = thr2_of(a, b);
-    const int flag = a.cta_flag[b];
-    for (int i = r0 + wave; i < r1; i += EWAVES) {
-        const unsigned long long ts = a.tstar[(long)b * a.N + i];
-        const float xi = l.x[i], yi = l.y[i], zi = l.z[i];
-        const int fi = l.fl[i];
-        int off = a.row_ptr[(long)b * (a.N + 1) + i];
-        for (int c0 = 0; c0 < a.N; c0 += 64) {
-            const bool m = member(a, l, i, c0 + lane, xi, yi, zi, fi, thr2, ts, flag);
-            const unsigned long long bm = __ballot(m);
-            if (m) {
-                const long p = (long)b * a.edge_cap + off + __popcll(bm & ((1ull << lane) - 1ull));
-                a.recv[p] = i;
-                a.send[p] = c0 + lane;
+    int* recv = a.recv + (long)b * a.edge_cap;
+    int* send = a.send + (long)b * a.edge_cap;
+    if (a.topk_active) {
+        for (int i = r0 + wave; i < r1; i += EWAVES) {
+            const int off = a.row_ptr[(long)b * (a.N + 1) + i];
+            const int d = a.deg[(long)b * a.N + i];
+            const bool row_tools = tools_on && (l.fl[i] & 1);
+            const int nt = row_tools ? ntool : 0;
+            const int nk = d - nt;                          // kept senders from the ELL row
+            const int* ell = a.ell + ((long)b * a.N + i) * a.k;
+            for (int t = lane; t < nk; t += 64) {
+                const int j = ell[t];
+                const int p = off + t + (row_tools ? l.tprefix[j] : 0);
+                recv[p] = i; send[p] = j;
             }
-            off += __popcll(bm);
+            for (int m = lane; m < nt; m += 64) {
+                const int j = l.tlist[m];
+                int before = 0;
+                for (int t = 0; t < nk; ++t) before += ell[t] < j ? 1 : 0;
+                const int p = off + m + before;
+                recv[p] = i; send[p] = j;
+            }
+        }
+    } else {
+        const float thr = thr_of(a, b);
+        const float thr2 = __fmul_rn(thr, thr);
+        for (int i = r0 + wave; i < r1; i += EWAVES) {
+            const float xi = l.x[i], yi = l.y[i], zi = l.z[i];
+            const int fi = l.fl[i];
+            int off = a.row_ptr[(long)b * (a.N + 1) + i];
+            // tool senders are not confined to surviving chunks: sweep every chunk when the tool rule is on
+            unsigned long long todo = (a.cta && flag) ? ~0ull : survivors(l, a.N, xi, yi, zi, thr);
+            const int nch = (a.N + 63) >> 6;
+            if (nch < 64) todo &= (1ull << nch) - 1ull;
+            while (todo) {
+                const int c = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const bool m = member_radius(a, l, i, 64 * c + lane, xi, yi, zi, fi, thr2, flag);
+                const unsigned long long bm = __ballot(m);
+                if (m) {
+                    const int p = off + __popcll(bm & lanes_below(lane));
+                    recv[p] = i; send[p] = 64 * c + lane;
+                }
+                off += __popcll(bm);
+            }
         }
     }
 }
@@ -305,7 +490,7 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     a.pos = h.pos; a.pos_bstride = h.pos_bstride; a.mask = h.mask; a.tool = h.tool; a.thr_vec = h.thr_vec; a.thr = h.thr;
     a.B = h.B; a.N = h.N; a.k = min(h.N, h.topk); a.topk_active = a.k < h.N; a.cta = h.cta; a.edge_cap = h.edge_cap;
     a.slices = h.slices; a.rows_per_slice = (h.N + h.slices - 1) / h.slices;
-    a.tstar = h.tstar; a.deg = h.deg; a.slice_tot = h.slice_tot; a.cta_flag = h.cta_flag;
+    a.ell = h.ell; a.deg = h.deg; a.slice_tot = h.slice_tot; a.cta_flag = h.cta_flag;
     a.recv = h.recv; a.send = h.send; a.row_ptr = h.row_ptr; a.n_edges = h.n_edges; a.overflow = h.overflow;
     a.max_nR = h.max_nR; a.zero_on_overflow = h.zero_on_overflow;
     const size_t lds = edge_lds_bytes(h.N);
@@ -328,6 +513,8 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     return hipGetLastError();
 }
 
-size_t edge_build_max_particles() { return 4096; }
+size_t edge_build_max_particles() { return MAXCH * 64; }
+// ints of ELL scratch per (candidate, particle)
+int edge_ell_stride(int N, int topk) { return topk < N ? topk : 0; }
 
 }  // namespace ag
