@@ -12,22 +12,30 @@
 //     cross-lane movement.  The K order this implies (feature 32t + (r&3) + 8(r>>2) + 4h for register (t,r),
 //     half h) is baked into the host-side weight packing (ag_api.hip: pack_layer).
 //   * Bias rides in the contraction: activation slot 150 is forced to 1.0, weight column 150 holds the bias.
-//   * The 160x152 weight panel of a layer (95 KB) is shared by the 8 wavefronts of a 512-thread workgroup through
-//     LDS, staged in two K-halves so the next half streams global->registers->LDS underneath the MFMAs of the
-//     current half (two 50 KB buffers).  One ds_read_b128 feeds 4 MFMAs per m-block.
+//   * The 160x152 weight panel of a layer (95 KB) is shared by the 4 wavefronts of a 256-thread workgroup through
+//     LDS, staged in four K-quarters so the next quarter streams global->registers->LDS underneath the MFMAs of
+//     the current one (two 25 KB buffers).  One ds_read_b128 feeds 4 MFMAs per m-block.  A workgroup is one
+//     wavefront per SIMD and 50 KB of LDS, so TWO workgroups share a CU and run unsynchronised: the prologue
+//     gathers, mid-chain row loads, epilogue stores and barrier waits of one hide under the MFMAs of the other
+//     (measured: one 8-wave workgroup per CU left the MFMA pipe idle 18-41 % of the time).
 //   * Roofline: fp32 MFMA (157.3 TFLOP/s).  Per 32 rows a 160-wide layer is 380 MFMAs = 2*32*160*152 FLOP.
 //   * Rows are independent columns of the MFMA, so results do not depend on which lane / workgroup / chunk / GPU a
 //     row lands in: sharded == unsharded bit-for-bit.
 #include "ag_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace ag {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int WG = 512;
-constexpr int WG_ROWS = 256;
-constexpr int BUF_FLOATS = HALF0_FLOATS;   // one LDS staging buffer (51,200 B)
+constexpr int WG = 256;                     // 4 wavefronts, one per SIMD; two workgroups share a CU
+constexpr int WG_ROWS = 128;
+constexpr int QCH = 5;                      // chunks (of 4 k-steps) per staged quarter: 5,5,5,4
+constexpr int BUF_FLOATS = QCH * CHUNK_FLOATS_MB5;   // one LDS staging buffer (25,600 B)
+constexpr int Q_FLOATS = BUF_FLOATS;        // quarters 0..2
+constexpr int Q3_FLOATS = (KCH - 3 * QCH) * CHUNK_FLOATS_MB5;
 
 struct Act { f32x16 t[5]; };
 
@@ -54,15 +62,22 @@ struct Stager {
 };
 
 // ------------------------------------------------------------------------------------------------ MFMA sweeps
-// chunks [Q0,Q1) of a layer whose LDS image starts at chunk Q0; input = previous accumulator tiles
+// chunks [Q0,Q1) of a layer whose LDS image starts at chunk Q0; input = previous accumulator tiles.
+// The weight fragments of chunk q+1 are read while the 4*MB MFMAs of chunk q execute (LDS latency would otherwise
+// be exposed once per chunk: hipcc issues the next ds_read only after the last MFMA of the chunk).
 template <int Q0, int Q1, int MB>
 __device__ __forceinline__ void mma_act(const float* wl, const Act& in, f32x16* acc, int lane) {
+    f32x4 a[MB], an[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) a[mb] = *reinterpret_cast<const f32x4*>(wl + mb * 256 + lane * 4);
 #pragma unroll
     for (int q = Q0; q < Q1; ++q) {
-        f32x4 a[MB];
+        if (q + 1 < Q1) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-            a[mb] = *reinterpret_cast<const f32x4*>(wl + ((q - Q0) * MB + mb) * 256 + lane * 4);
+            for (int mb = 0; mb < MB; ++mb)
+                an[mb] = *reinterpret_cast<const f32x4*>(wl + ((q + 1 - Q0) * MB + mb) * 256 + lane * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int s = 4 * q + e;
@@ -73,6 +88,10 @@ __device__ __forceinline__ void mma_act(const float* wl, const Act& in, f32x16* 
             for (int mb = 0; mb < MB; ++mb)
                 acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][e], b, acc[mb], 0, 0, 0);
         }
+        // pin the order: reads of q+1, then the MFMAs of q (and keep the one-m-block head from hoisting all 19 reads)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) a[mb] = an[mb];
     }
 }
 
@@ -102,12 +121,20 @@ __device__ __forceinline__ void zero(Act& a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) a.t[t][r] = 0.0f;
 }
+// Forces the 80 values to exist in registers HERE.  Without it the compiler sinks elementwise work (the residual
+// adds + ReLU) into the next layer's MFMA sweep, next to each first use, and keeps the loaded operands alive by
+// spilling ~100 VGPRs to scratch (seen in k_node_prop<true>, which has no store that would pin the values).
+__device__ __forceinline__ void materialize(Act& a) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t) asm volatile("" : "+v"(a.t[t]));
+}
 __device__ __forceinline__ void relu_one(Act& a, int lane) {   // ReLU, then force slot 150 (tile 4, reg 10, upper half) to 1
 #pragma unroll
     for (int t = 0; t < 5; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a.t[t][r] = __builtin_fmaxf(a.t[t][r], 0.0f);
     a.t[4][10] = lane >= 32 ? 1.0f : a.t[4][10];
+    materialize(a);
 }
 __device__ __forceinline__ void set_one(Act& a, int lane) { a.t[4][10] = lane >= 32 ? 1.0f : a.t[4][10]; }
 
@@ -133,6 +160,20 @@ __device__ __forceinline__ void add_rows(Act& a, const float* __restrict__ base,
             a.t[t][4 * q + 0] += v[0]; a.t[t][4 * q + 1] += v[1]; a.t[t][4 * q + 2] += v[2]; a.t[t][4 * q + 3] += v[3];
         }
 }
+// returns 0, but only after `v` has been computed, and the compiler cannot see that it is 0
+__device__ __forceinline__ long pin_after(Act& a) {
+    int z = 0;
+    float v = a.t[0][0];
+    asm volatile("" : "+v"(z), "+v"(v));
+    a.t[0][0] = v;
+    return z;
+}
+__device__ __forceinline__ void add_act(Act& a, const Act& b) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.t[t][r] += b.t[t][r];
+}
 __device__ __forceinline__ void store_rows(const Act& a, float* __restrict__ base, long row, int lane, bool valid) {
     if (!valid) return;
     float* p = base + row * NFP + 4 * (lane >> 5);
@@ -146,24 +187,45 @@ __device__ __forceinline__ void store_rows(const Act& a, float* __restrict__ bas
         }
 }
 
-// One full 160-wide layer.  Precondition: its K-half 0 is in LDS buffer 0 and a barrier has passed.
-// Streams K-half 1 into buffer 1 under the first sweep and the NEXT phase (NEXT floats from `next`) into buffer 0
-// under the second.  Postcondition: `next` is in buffer 0 and a barrier has passed (if NEXT > 0).
+// One full 160-wide layer, weights streamed in four K-quarters through two LDS buffers.
+// Precondition: quarter 0 is in buffer 0 and a barrier has passed.  Every sweep runs with the NEXT quarter's
+// global->register loads in flight; the registers are written to the other buffer after the sweep.
+// Postcondition: the first NEXT floats of `next` (the following phase) are in buffer 0 and a barrier has passed.
 template <int NEXT>
 __device__ __forceinline__ void layer160(float* lds, const float* __restrict__ w, const float* __restrict__ next,
                                          const Act& in, Act& out, int tid, int lane) {
-    Stager<HALF1_FLOATS> s1;
-    s1.load(w + HALF0_FLOATS, tid);
+    float* b0 = lds;
+    float* b1 = lds + BUF_FLOATS;
     zero(out);
-    mma_act<0, KCH_H0, 5>(lds, in, out.t, lane);
-    s1.store(lds + BUF_FLOATS, tid);
-    __syncthreads();
-    Stager<NEXT> s2;
-    if (NEXT > 0) s2.load(next, tid);
-    mma_act<KCH_H0, KCH, 5>(lds + BUF_FLOATS, in, out.t, lane);
-    if (NEXT > 0) {
-        s2.store(lds, tid);
+    {
+        Stager<Q_FLOATS> s;
+        s.load(w + Q_FLOATS, tid);
+        mma_act<0, QCH, 5>(b0, in, out.t, lane);
+        s.store(b1, tid);
         __syncthreads();
+    }
+    {
+        Stager<Q_FLOATS> s;
+        s.load(w + 2 * Q_FLOATS, tid);
+        mma_act<QCH, 2 * QCH, 5>(b1, in, out.t, lane);
+        s.store(b0, tid);
+        __syncthreads();
+    }
+    {
+        Stager<Q3_FLOATS> s;
+        s.load(w + 3 * Q_FLOATS, tid);
+        mma_act<2 * QCH, 3 * QCH, 5>(b0, in, out.t, lane);
+        s.store(b1, tid);
+        __syncthreads();
+    }
+    {
+        Stager<NEXT> s;
+        if (NEXT > 0) s.load(next, tid);
+        mma_act<3 * QCH, KCH, 5>(b1, in, out.t, lane);
+        if (NEXT > 0) {
+            s.store(b0, tid);
+            __syncthreads();
+        }
     }
 }
 
@@ -182,6 +244,7 @@ struct GDev {
     const int* recv; const int* send; const int* row_ptr; const int* n_edges;
     int B, N, n_p, n_inst, edge_cap, c_cap;
     float clamp; float* pred_pos; float* pred_motion;
+    unsigned long long* dbg;   // diagnostic build of the clock probe only: 4 stamps per workgroup, never read by kernels
 };
 
 using WL = WeightLayout;
@@ -196,10 +259,14 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
     const int e0 = (int)(wg_row0 - (long)b * g.c_cap);
     const int ne = g.n_edges[b];
     if (e0 >= ne) return;                                    // whole workgroup past this candidate's edges
+    if (g.dbg && tid == 0) {
+        g.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        g.dbg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 
     // small first-layer panel -> buffer 1; under its MFMAs, L2 half 0 -> buffer 0
     stage_now<EDGE_L1_CHUNKS * CHUNK_FLOATS_MB5>(lds + BUF_FLOATS, g.w + WL::E_L1, tid);
-    Stager<HALF0_FLOATS> sn;
+    Stager<Q_FLOATS> sn;
     sn.load(g.w + WL::E_L2, tid);
 
     const int el = e0 + wave * 32 + (lane & 31);
@@ -232,12 +299,16 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
     sn.store(lds, tid);
     __syncthreads();
     relu_one(y, lane);
-    layer160<HALF0_FLOATS>(lds, g.w + WL::E_L2, g.w + WL::E_L3, y, x, tid, lane);
+    layer160<Q_FLOATS>(lds, g.w + WL::E_L2, g.w + WL::E_L3, y, x, tid, lane);
     relu_one(x, lane);
-    layer160<HALF0_FLOATS>(lds, g.w + WL::E_L3, g.w + WL::E_W1, x, y, tid, lane);
+    layer160<Q_FLOATS>(lds, g.w + WL::E_L3, g.w + WL::E_W1, x, y, tid, lane);
     relu_one(y, lane);
     layer160<0>(lds, g.w + WL::E_W1, nullptr, y, x, tid, lane);
     store_rows(x, g.C, (long)b * g.c_cap + el, lane, valid);
+    if (g.dbg && tid == 0) {
+        g.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+        g.dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ node encode chain
@@ -252,7 +323,7 @@ __global__ __launch_bounds__(WG, 2) void k_node_enc(GDev g) {
     const long rowc = valid ? row : nrows - 1;
 
     stage_now<NODE_L1_CHUNKS * CHUNK_FLOATS_MB5>(lds + BUF_FLOATS, g.w + WL::N_L1, tid);
-    Stager<HALF0_FLOATS> sn;
+    Stager<Q_FLOATS> sn;
     sn.load(g.w + WL::N_L2, tid);
     float f[8];
     {
@@ -266,14 +337,14 @@ __global__ __launch_bounds__(WG, 2) void k_node_enc(GDev g) {
     sn.store(lds, tid);
     __syncthreads();
     relu_one(y, lane);
-    layer160<HALF0_FLOATS>(lds, g.w + WL::N_L2, g.w + WL::N_L3, y, x, tid, lane);
+    layer160<Q_FLOATS>(lds, g.w + WL::N_L2, g.w + WL::N_L3, y, x, tid, lane);
     relu_one(x, lane);
-    layer160<HALF0_FLOATS>(lds, g.w + WL::N_L3, g.w + WL::N_WA, x, y, tid, lane);
+    layer160<Q_FLOATS>(lds, g.w + WL::N_L3, g.w + WL::N_WA, x, y, tid, lane);
     relu_one(y, lane);                                       // y = p_enc (slot 150 = 1 for the bias of Wa)
     store_rows(y, g.eff, row, lane, valid);
-    layer160<HALF0_FLOATS>(lds, g.w + WL::N_WA, g.w + WL::N_W2, y, x, tid, lane);
+    layer160<Q_FLOATS>(lds, g.w + WL::N_WA, g.w + WL::N_W2, y, x, tid, lane);
     store_rows(x, g.P, row, lane, valid);
-    layer160<HALF0_FLOATS>(lds, g.w + WL::N_W2, g.w + WL::N_W3, y, x, tid, lane);
+    layer160<Q_FLOATS>(lds, g.w + WL::N_W2, g.w + WL::N_W3, y, x, tid, lane);
     store_rows(x, g.U, row, lane, valid);
     layer160<0>(lds, g.w + WL::N_W3, nullptr, y, x, tid, lane);
     store_rows(x, g.V, row, lane, valid);
@@ -292,24 +363,29 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     const bool valid = row < nrows;
     const long rowc = valid ? row : nrows - 1;
 
-    Stager<HALF0_FLOATS> sn;
+    Stager<Q_FLOATS> sn;
     sn.load(g.w + WL::P_WB, tid);
     Act x, y;
     load_rows(x, g.agg, rowc, lane);
     sn.store(lds, tid);
     __syncthreads();
-    layer160<HALF0_FLOATS>(lds, g.w + WL::P_WB, g.w + (LAST ? WL::P_P0 : WL::N_W2), x, y, tid, lane);
-    add_rows(y, g.P, rowc, lane);
-    add_rows(y, g.eff, rowc, lane);
+    layer160<Q_FLOATS>(lds, g.w + WL::P_WB, g.w + (LAST ? WL::P_P0 : WL::N_W2), x, y, tid, lane);
+    // x (the agg tile) is dead: reuse its 80 registers as the landing zone, one operand at a time.  Left to itself
+    // the compiler issues both 80-register row loads up front on top of the live accumulators and spills ~80 VGPRs;
+    // an opaque zero added to the row index, data-dependent on the accumulator, pins each load group in place.
+    load_rows(x, g.P, rowc + pin_after(y), lane);
+    add_act(y, x);
+    load_rows(x, g.eff, rowc + pin_after(y), lane);
+    add_act(y, x);
     relu_one(y, lane);                                       // y = new particle effect (slot 150 forced to 1)
     if (!LAST) {
         store_rows(y, g.eff, row, lane, valid);
-        layer160<HALF0_FLOATS>(lds, g.w + WL::N_W2, g.w + WL::N_W3, y, x, tid, lane);
+        layer160<Q_FLOATS>(lds, g.w + WL::N_W2, g.w + WL::N_W3, y, x, tid, lane);
         store_rows(x, g.U, row, lane, valid);
         layer160<0>(lds, g.w + WL::N_W3, nullptr, y, x, tid, lane);
         store_rows(x, g.V, row, lane, valid);
     } else {
-        layer160<HALF0_FLOATS>(lds, g.w + WL::P_P0, g.w + WL::P_P1, y, x, tid, lane);
+        layer160<Q_FLOATS>(lds, g.w + WL::P_P0, g.w + WL::P_P1, y, x, tid, lane);
         relu_one(x, lane);
         layer160<OUT3_FLOATS>(lds, g.w + WL::P_P1, g.w + WL::P_P2, x, y, tid, lane);
         relu_one(y, lane);
@@ -339,13 +415,40 @@ static GDev to_dev(const float* w, const GraphBufs& g) {
     d.V = g.V; d.agg = g.agg; d.C = g.C; d.recv = g.recv; d.send = g.send; d.row_ptr = g.row_ptr;
     d.n_edges = g.n_edges; d.B = g.B; d.N = g.N; d.n_p = g.n_p; d.n_inst = g.n_inst; d.edge_cap = g.edge_cap;
     d.c_cap = g.c_cap; d.clamp = 0; d.pred_pos = nullptr; d.pred_motion = nullptr;
+    d.dbg = nullptr;
     return d;
 }
 static int node_grid(const GraphBufs& g) { return (int)(((long)g.B * g.N + WG_ROWS - 1) / WG_ROWS); }
 
 hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
     const long rows = (long)g.B * g.c_cap;
-    hipLaunchKernelGGL(k_edge_enc, dim3((unsigned)(rows / WG_ROWS)), dim3(WG), 0, st, to_dev(w, g));
+    const unsigned nwg = (unsigned)(rows / WG_ROWS);
+    GDev d = to_dev(w, g);
+    // AG_CLOCK_PROBE=n : diagnostic mode (synchronises!): stamp the first n launches and print the in-kernel clock
+    static int probe_left = getenv("AG_CLOCK_PROBE") ? atoi(getenv("AG_CLOCK_PROBE")) : 0;
+    static unsigned long long* dbg = nullptr;
+    static unsigned dbg_cap = 0;
+    if (probe_left > 0) {
+        if (dbg_cap < nwg) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, (size_t)nwg * 32); dbg_cap = nwg; }
+        (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 32, st);
+        d.dbg = dbg;
+    }
+    hipLaunchKernelGGL(k_edge_enc, dim3(nwg), dim3(WG), 0, st, d);
+    if (probe_left > 0) {
+        --probe_left;
+        (void)hipStreamSynchronize(st);
+        unsigned long long* h = (unsigned long long*)malloc((size_t)nwg * 32);
+        (void)hipMemcpy(h, dbg, (size_t)nwg * 32, hipMemcpyDeviceToHost);
+        double sum = 0, sumc = 0; int n = 0; double mn = 1e9, mx = 0;
+        for (unsigned i = 0; i < nwg; ++i) {
+            if (!h[4 * i + 3] || h[4 * i + 3] == h[4 * i + 1]) continue;
+            const double cyc = (double)(h[4 * i + 2] - h[4 * i + 0]), rt = (double)(h[4 * i + 3] - h[4 * i + 1]);
+            const double ghz = cyc / rt * 0.1;   // s_memrealtime ticks at 100 MHz
+            sum += ghz; sumc += cyc; ++n; mn = ghz < mn ? ghz : mn; mx = ghz > mx ? ghz : mx;
+        }
+        if (n) fprintf(stderr, "[ag clock probe] k_edge_enc: %d workgroups, in-kernel clock mean %.3f GHz (min %.3f max %.3f), mean WG lifetime %.0f cycles\n", n, sum / n, mn, mx, sumc / n);
+        free(h);
+    }
     return hipGetLastError();
 }
 hipError_t launch_node_enc(const float* w, const GraphBufs& g, hipStream_t st) {
