@@ -48,6 +48,12 @@ struct ag_ctx {
     int* d_repeat = nullptr; size_t repeat_cap = 0;
     std::vector<int> h_repeat;   // ctx-owned copy so the caller's array may die right after the call
     int* d_overflow = nullptr;
+    // second in-library stream: alternate chunks run on it so that the HBM-bound kernels of one chunk overlap the
+    // MFMA-bound chains of the other (fork/join with events around every rollout call)
+    static constexpr int kMaxStreams = 4;
+    hipStream_t aux_stream[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused: the caller's stream
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
+    int n_streams = 2;
     // profiling
     unsigned prof_mask = 0;
     std::vector<ProfEvent> prof_live;
@@ -154,18 +160,21 @@ int ensure_slab(ag_ctx* c, size_t bytes) {
     return AG_OK;
 }
 
-// carve a workspace for Bc candidates.  own_edges: allocate edge index arrays + builder scratch; roll: rollout state
-int make_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices, bool own_edges,
-              bool roll, bool own_group, int N_o, int ell_stride) {
+// bytes of one workspace for Bc candidates.  own_edges: edge index arrays + builder scratch; roll: rollout state
+size_t work_bytes(int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices, bool own_edges, bool roll,
+                  bool own_group, int N_o, int ell_stride) {
     const size_t rows = (size_t)Bc * N;
-    size_t bytes = 0;
-    bytes += 16 * 256;
+    size_t bytes = 16 * 256;
     bytes += rows * (NODE_IN + F12 + (own_group ? n_inst : 0)) * 4 + 5 * rows * NFP * 4 + (size_t)Bc * c_cap * NFP * 4;
     if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 2) * 4 + 2 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
     if (roll) bytes += (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows;
-    bytes += 64 * 256;
-    int rc = ensure_slab(c, bytes);
-    if (rc) return rc;
+    return bytes + 64 * 256;
+}
+
+// carve one workspace from the slab (which must already be large enough; see work_bytes)
+int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices, bool own_edges,
+               bool roll, bool own_group, int N_o, int ell_stride) {
+    const size_t rows = (size_t)Bc * N;
     Slab& s = c->slab;
     w.g.node_in = s.take<float>(rows * NODE_IN);
     w.g.feat12 = s.take<float>(rows * F12);
@@ -200,7 +209,7 @@ int make_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int c
 }
 
 int pick_slices(int B, int N) {
-    int s = (512 + B - 1) / B;
+    int s = (512 + B - 1) / B;     // ~512 sixteen-wave workgroups per launch
     s = std::min(s, std::max(1, N / 64));
     return std::max(1, std::min(s, 64));
 }
@@ -264,6 +273,11 @@ int ag_ctx_destroy(ag_ctx* c) {
     (void)hipSetDevice(c->device);
     for (auto& p : c->prof_live) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int i = 1; i < ag_ctx::kMaxStreams; ++i) {
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+        if (c->aux_stream[i]) (void)hipStreamDestroy(c->aux_stream[i]);
+    }
     if (c->d_w) (void)hipFree(c->d_w);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
     if (c->d_repeat) (void)hipFree(c->d_repeat);
@@ -354,7 +368,9 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
     const int Bc = auto_chunk(c, B, N);
     const int c_cap = (int)round_up(edge_cap, 256);
     Work w{};
-    int rc = make_work(c, w, Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0);
+    int rc = ensure_slab(c, work_bytes(Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0));
+    if (rc) return rc;
+    rc = carve_work(c, w, Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0);
     if (rc) return rc;
     for (int b0 = 0; b0 < B; b0 += Bc) {
         const int nb = std::min(Bc, B - b0);
@@ -405,14 +421,42 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     const int k = std::min(N, p->topk);
     const long bound = (long)N * (k + p->M);                 // in-degree <= topk + M (radius-AND-top-k, then tool rule)
     const int edge_cap = (int)round_up((size_t)std::min<long>(bound, p->max_nR), 256);
-    const int Bc = auto_chunk(c, p->B, N);
+    int ns = std::max(1, std::min(c->n_streams, (int)ag_ctx::kMaxStreams));
+    if (const char* e = getenv("AG_STREAMS")) ns = std::max(1, std::min(atoi(e), (int)ag_ctx::kMaxStreams));
+    if (c->prof_mask) ns = 1;   // per-kernel event times are only meaningful without cross-stream interference
+    int Bc = auto_chunk(c, p->B, N);
+    if (ns > 1) Bc = std::min(Bc, (p->B + ns - 1) / ns);      // at least one chunk per stream
+    if (p->B <= 1) ns = 1;
     const int slices = pick_slices(Bc, N);
-    Work w{};
-    rc = make_work(c, w, Bc, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, edge_ell_stride(N, p->topk));
+    const int ell = edge_ell_stride(N, p->topk);
+    const size_t wb = work_bytes(Bc, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
+    rc = ensure_slab(c, wb * ns);
     if (rc) return rc;
+    Work ws[ag_ctx::kMaxStreams];
+    for (int i = 0; i < ns; ++i) {
+        rc = carve_work(c, ws[i], Bc, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
+        if (rc) return rc;
+    }
+    hipStream_t streams[ag_ctx::kMaxStreams] = {st, st, st, st};
+    if (ns > 1) {
+        if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));            // inputs / memset / repeat upload are ordered before
+        for (int i = 1; i < ns; ++i) {
+            if (!c->aux_stream[i]) {
+                HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+            }
+            streams[i] = c->aux_stream[i];
+            HIPCHK(c, hipStreamWaitEvent(c->aux_stream[i], c->ev_fork, 0));
+        }
+    }
 
-    for (int b0 = 0; b0 < p->B; b0 += Bc) {
+    int ci = 0;
+    for (int b0 = 0; b0 < p->B; b0 += Bc, ++ci) {
         const int nb = std::min(Bc, p->B - b0);
+        Work& w = ws[ci % ns];
+        hipStream_t cs = streams[ci % ns];
+        c->prof_stream = cs;
         GraphBufs g = w.g;
         g.B = nb; g.n_p = p->N_o;
         RollArgs ra{};
@@ -431,16 +475,21 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
             int max_rep = 0;
             for (int b = 0; b < nb; ++b) max_rep = std::max(max_rep, h_repeat[(size_t)(b0 + b) * p->H + li]);
             ra.li = li; ra.ai = 0;
-            { Scoped s(c, FAM_ROLL_INIT); HIPCHK(c, launch_roll_init(ra, w.r, g, st)); }
+            { Scoped s(c, FAM_ROLL_INIT); HIPCHK(c, launch_roll_init(ra, w.r, g, cs)); }
             for (int ai = 1; ai <= max_rep; ++ai) {           // forward_dynamics.py:156
-                HIPCHK(c, launch_edge_build(ea, st, prof_mark, c));
-                rc = run_model(c, g, w.r.pred, w.r.motion, st);
+                HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));
+                rc = run_model(c, g, w.r.pred, w.r.motion, cs);
                 if (rc) return rc;
                 ra.ai = ai;
-                { Scoped s(c, FAM_ROLL_UPDATE); HIPCHK(c, launch_roll_update(ra, w.r, g, st)); }
+                { Scoped s(c, FAM_ROLL_UPDATE); HIPCHK(c, launch_roll_update(ra, w.r, g, cs)); }
             }
         }
     }
+    for (int i = 1; i < ns; ++i) {
+        HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux_stream[i]));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[i], 0));
+    }
+    c->prof_stream = st;
     return AG_OK;
 }
 

@@ -34,7 +34,8 @@
 
 namespace ag {
 
-constexpr int EW = 1024;          // threads per workgroup (16 wavefronts)
+constexpr int EW = 1024;          // threads per workgroup (16 wavefronts).  256-thread workgroups that could sit beside
+                                  // the MLP chains of another stream were measured: 1.8x slower alone, no net gain.
 constexpr int EWAVES = EW / 64;
 constexpr int CAP = 256;          // candidate-buffer entries per wavefront
 constexpr int MAXCH = 64;         // sender chunks per candidate (N <= 4096)
@@ -60,35 +61,34 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 __device__ __forceinline__ unsigned long long lanes_below(int lane) { return (1ull << lane) - 1ull; }
 
-// LDS carve.  The 32 KB candidate-key area of k_edge_count is reused by k_edge_emit for its scan / tool tables.
+// LDS carve
 struct EdgeLds {
     unsigned long long* keys;   // [EWAVES][CAP]                                   (count kernel)
-    int* scan;                  // [EW]                                            (emit kernel, overlays keys)
-    unsigned short* tprefix;    // [Np+4] number of tools with index < j           (emit kernel, overlays keys)
-    unsigned short* tlist;      // [Np]   tool indices in ascending order          (emit kernel, overlays keys)
+    int* scan;                  // [EW]                                            (emit kernel)
+    unsigned short* tprefix;    // [Np+4] number of tools with index < j           (emit kernel)
+    unsigned short* tlist;      // [Np]   tool indices in ascending order          (emit kernel)
     float* x; float* y; float* z;
     float* bb;                  // [6][MAXCH] chunk boxes: minx maxx miny maxy minz maxz
     int* misc;                  // [64]  0: cta flag, 1: slice total, 2: tool count
     uint8_t* fl;                // [Np] bit0 valid, bit1 tool
 };
-static_assert(EW * 4 + 2 * (MAXCH * 64 + 4) * 2 <= EWAVES * CAP * 8, "emit tables must fit in the key area");
 __host__ __device__ inline size_t edge_lds_bytes(int N) {
     const size_t Np = (size_t)((N + 3) & ~3);
-    return (size_t)EWAVES * CAP * 8 + Np * 12 + 6 * MAXCH * 4 + 64 * 4 + Np + 16;
+    return (size_t)EWAVES * CAP * 8 + EW * 4 + (2 * Np + 8) * 2 + Np * 12 + 6 * MAXCH * 4 + 64 * 4 + Np + 16;
 }
 __device__ __forceinline__ EdgeLds carve(unsigned char* base, int N) {
     EdgeLds l;
     const int Np = (N + 3) & ~3;
     l.keys = reinterpret_cast<unsigned long long*>(base);
-    l.scan = reinterpret_cast<int*>(base);
-    l.tprefix = reinterpret_cast<unsigned short*>(base + EW * 4);
-    l.tlist = l.tprefix + Np + 4;
-    l.x = reinterpret_cast<float*>(base + (size_t)EWAVES * CAP * 8);
+    l.scan = reinterpret_cast<int*>(base + (size_t)EWAVES * CAP * 8);
+    l.x = reinterpret_cast<float*>(l.scan + EW);
     l.y = l.x + Np;
     l.z = l.y + Np;
     l.bb = l.z + Np;
     l.misc = reinterpret_cast<int*>(l.bb + 6 * MAXCH);
-    l.fl = reinterpret_cast<uint8_t*>(l.misc + 64);
+    l.tprefix = reinterpret_cast<unsigned short*>(l.misc + 64);
+    l.tlist = l.tprefix + Np + 4;
+    l.fl = reinterpret_cast<uint8_t*>(l.tlist + Np + 4);
     return l;
 }
 

@@ -20,7 +20,8 @@ struct MpDev {
     const int* send; const int* row_ptr;
     int B, N, edge_cap, c_cap;
 };
-__global__ __launch_bounds__(MP_WAVES * 64) void k_mp(MpDev g) {
+// <= 64 VGPRs (8 waves/SIMD bound) so that one k_mp wavefront fits on a SIMD beside two MLP-chain wavefronts
+__global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * MP_WAVES + (threadIdx.x >> 6);
     if (row >= (long)g.B * g.N) return;

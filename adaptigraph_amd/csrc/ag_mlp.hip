@@ -63,21 +63,16 @@ struct Stager {
 
 // ------------------------------------------------------------------------------------------------ MFMA sweeps
 // chunks [Q0,Q1) of a layer whose LDS image starts at chunk Q0; input = previous accumulator tiles.
-// The weight fragments of chunk q+1 are read while the 4*MB MFMAs of chunk q execute (LDS latency would otherwise
-// be exposed once per chunk: hipcc issues the next ds_read only after the last MFMA of the chunk).
+// (Reading the fragments of chunk q+1 under the MFMAs of chunk q was measured: no gain - the second wavefront on the
+// SIMD already covers the LDS latency - and +20 VGPRs, which would evict the co-resident k_mp wavefront.)
 template <int Q0, int Q1, int MB>
 __device__ __forceinline__ void mma_act(const float* wl, const Act& in, f32x16* acc, int lane) {
-    f32x4 a[MB], an[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) a[mb] = *reinterpret_cast<const f32x4*>(wl + mb * 256 + lane * 4);
 #pragma unroll
     for (int q = Q0; q < Q1; ++q) {
-        if (q + 1 < Q1) {
+        f32x4 a[MB];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-                an[mb] = *reinterpret_cast<const f32x4*>(wl + ((q + 1 - Q0) * MB + mb) * 256 + lane * 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int mb = 0; mb < MB; ++mb)
+            a[mb] = *reinterpret_cast<const f32x4*>(wl + ((q - Q0) * MB + mb) * 256 + lane * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int s = 4 * q + e;
@@ -88,10 +83,8 @@ __device__ __forceinline__ void mma_act(const float* wl, const Act& in, f32x16* 
             for (int mb = 0; mb < MB; ++mb)
                 acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][e], b, acc[mb], 0, 0, 0);
         }
-        // pin the order: reads of q+1, then the MFMAs of q (and keep the one-m-block head from hoisting all 19 reads)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) a[mb] = an[mb];
+        // one m-block: nothing else stops the scheduler from hoisting all 19 weight reads (76 VGPRs)
+        if (MB == 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -1,0 +1,72 @@
+"""CPU checks of the boundary: the shared library loads without a GPU and exports exactly the header's symbols."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "adaptigraph_amd.h")
+
+
+def _header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ag_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from adaptigraph_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = _lib.load()
+    declared = _header_functions()
+    assert declared == sorted(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ag_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r" T (ag_[a-z_]+)$", out, flags=re.M)))
+    assert exported == declared, (exported, declared)
+
+
+def test_no_cpu_fallback():
+    import torch
+    import adaptigraph_amd as ag
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ag.construct_edges_from_states_batch(torch.zeros(1, 4, 3), 0.5, torch.ones(1, 4, dtype=torch.bool),
+                                             torch.zeros(1, 4, dtype=torch.bool))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ag.Engine("cpu")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "adaptigraph_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text, f"{f} mentions the oracle: the product path must not depend on it"
+
+
+def test_host_shim_tool_layout_matches_oracle():
+    """Host logic on CPU: decode_action + tool keypoint layout (forward_dynamics.py:23,42-75) vs the oracle."""
+    import numpy as np
+    import torch
+    from adaptigraph_amd.forward_dynamics import _tool_layout
+    from adaptigraph_amd.plan_utils import decode_action
+    from oracle import adaptigraph_oracle as O
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-3, 3, (5, 3, 4)).astype(np.float32)
+    a[..., 3] = rng.uniform(2, 15, (5, 3))
+    for pts in ([[0, 0, 0.12]], [[0, 0, 0.1], [0, 0.05, 0.1], [0, 0.025, 0.1], [0, -0.025, 0.1], [0, -0.05, 0.1]]):
+        task = {"pusher_points": pts, "sim_real_ratio": 10, "push_length": 0.2}
+        dec, rep = decode_action(torch.from_numpy(a), push_length=0.2)
+        xz, delta = _tool_layout(dec, torch.from_numpy(a[..., 2]), task)
+        odec, orep = O.decode_action(a, 0.2)
+        oxz, odelta = O.tool_keypoints(odec, a[..., 2], task)
+        assert np.array_equal(dec.numpy(), odec) and np.array_equal(rep.numpy(), orep)
+        assert np.array_equal(xz.numpy(), oxz) and np.array_equal(delta.numpy(), odelta)

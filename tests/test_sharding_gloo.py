@@ -1,0 +1,61 @@
+"""Row (e) of SURVEY §8 on CPU: 2-rank gloo run of the sharding + cost all-gather logic (no GPU compute here)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from adaptigraph_amd.sharding import shard_bounds, all_gather_costs, sharded_rollout_costs
+
+
+def test_shard_bounds_cover_batch():
+    for B in (1, 7, 64, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(B, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, B, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)                                   # every rank draws the same action batch
+    actions = torch.rand(B, 2, 4)
+
+    def fake_rollout(a):                                   # stands in for dynamics(): per-candidate, deterministic
+        return a.sum(-1, keepdim=True).repeat(1, 1, 5)     # (b, H, 5)
+
+    def cost(seq):
+        return seq[:, -1].mean(-1)
+
+    full = sharded_rollout_costs(fake_rollout, cost, actions)
+    want = cost(fake_rollout(actions))
+    ok = torch.equal(full, want)                           # sharded == unsharded, bit for bit
+    lo, hi = shard_bounds(B, world, rank)
+    ok = ok and torch.equal(all_gather_costs(want[lo:hi], B), want)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_matches_unsharded():
+    ctx = mp.get_context("spawn")
+    for B in (64, 65):                                     # even and ragged split
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert sorted(res) == [(0, True), (1, True)]
