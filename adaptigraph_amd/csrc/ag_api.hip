@@ -167,7 +167,8 @@ size_t work_bytes(int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices
     size_t bytes = 16 * 256;
     bytes += rows * (NODE_IN + F12 + (own_group ? n_inst : 0)) * 4 + 5 * rows * NFP * 4 + (size_t)Bc * c_cap * NFP * 4;
     if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 2) * 4 + 2 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
-    if (roll) bytes += (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows;
+    if (roll) bytes += (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
+                       (size_t)cls_rows(N_o, N - N_o, Bc) * (NODE_IN + 4 * NFP) * 4;
     return bytes + 64 * 256;
 }
 
@@ -203,6 +204,13 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
         w.r.motion = s.take<float>((size_t)Bc * N_o * 3);
         w.r.mask = s.take<uint8_t>(rows);
         w.r.tool = s.take<uint8_t>(rows);
+        const size_t cr = (size_t)cls_rows(N_o, N - N_o, Bc);
+        w.g.cls_on = 1; w.g.N_o = N_o; w.g.M = N - N_o; w.g.vmask = w.r.mask;
+        w.g.c_node_in = s.take<float>(cr * NODE_IN);
+        w.g.c_eff = s.take<float>(cr * NFP);
+        w.g.c_P = s.take<float>(cr * NFP);
+        w.g.c_U = s.take<float>(cr * NFP);
+        w.g.c_V = s.take<float>(cr * NFP);
     }
     if (s.used > s.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
     return AG_OK;
@@ -224,14 +232,15 @@ int auto_chunk(const ag_ctx* c, int B, int N) {
     return (int)std::max(1L, std::min<long>(bc, B));
 }
 
-// one model forward on a prepared workspace (node_in, feat12, group, edges all set)
+// one model forward on a prepared workspace (node_in, feat12, group, edges all set).  With g.cls_on the particle
+// encoder outputs already sit in the class table (encoded at look-ahead-step start) and k_node_enc is skipped.
 int run_model(ag_ctx* c, const GraphBufs& g, float* pred_pos, float* pred_motion, hipStream_t st) {
-    { Scoped p(c, FAM_NODE_ENC); HIPCHK(c, launch_node_enc(c->d_w, g, st)); }
+    if (!g.cls_on) { Scoped p(c, FAM_NODE_ENC); HIPCHK(c, launch_node_enc(c->d_w, g, 0, (long)g.B * g.N, st)); }
     { Scoped p(c, FAM_EDGE_ENC); HIPCHK(c, launch_edge_enc(c->d_w, g, st)); }
     for (int ps = 0; ps < c->dims.pstep; ++ps) {
-        { Scoped p(c, FAM_MP); HIPCHK(c, launch_mp(g, st)); }
-        if (ps + 1 < c->dims.pstep) { Scoped p(c, FAM_NODE_PROP); HIPCHK(c, launch_node_prop(c->d_w, g, st)); }
-        else { Scoped p(c, FAM_NODE_FINAL); HIPCHK(c, launch_node_final(c->d_w, g, c->dims.motion_clamp, pred_pos, pred_motion, st)); }
+        { Scoped p(c, FAM_MP); HIPCHK(c, launch_mp(g, ps == 0, st)); }
+        if (ps + 1 < c->dims.pstep) { Scoped p(c, FAM_NODE_PROP); HIPCHK(c, launch_node_prop(c->d_w, g, ps == 0, st)); }
+        else { Scoped p(c, FAM_NODE_FINAL); HIPCHK(c, launch_node_final(c->d_w, g, ps == 0, c->dims.motion_clamp, pred_pos, pred_motion, st)); }
     }
     return AG_OK;
 }
@@ -451,6 +460,7 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         }
     }
 
+    bool obj_cls_ready[ag_ctx::kMaxStreams] = {false, false, false, false};   // per workspace, per call
     int ci = 0;
     for (int b0 = 0; b0 < p->B; b0 += Bc, ++ci) {
         const int nb = std::min(Bc, p->B - b0);
@@ -475,7 +485,15 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
             int max_rep = 0;
             for (int b = 0; b < nb; ++b) max_rep = std::max(max_rep, h_repeat[(size_t)(b0 + b) * p->H + li]);
             ra.li = li; ra.ai = 0;
+            // masked variant: the object rows depend on nothing per-candidate either (both validity variants are
+            // tabulated), so they are encoded once per call and workspace; tool rows once per look-ahead step
+            ra.write_obj_cls = obj_cls_ready[ci % ns] ? 0 : 1;
             { Scoped s(c, FAM_ROLL_INIT); HIPCHK(c, launch_roll_init(ra, w.r, g, cs)); }
+            { Scoped s(c, FAM_NODE_ENC);
+              const long tool0 = 2L * p->N_o;
+              if (!obj_cls_ready[ci % ns]) HIPCHK(c, launch_node_enc(c->d_w, g, 0, tool0 + (long)nb * p->M, cs));
+              else HIPCHK(c, launch_node_enc(c->d_w, g, tool0, (long)nb * p->M, cs)); }
+            obj_cls_ready[ci % ns] = true;
             for (int ai = 1; ai <= max_rep; ++ai) {           // forward_dynamics.py:156
                 HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));
                 rc = run_model(c, g, w.r.pred, w.r.motion, cs);

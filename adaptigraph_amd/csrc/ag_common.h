@@ -93,13 +93,25 @@ struct GraphBufs {
     int B, N, n_p, n_inst;
     int edge_cap;     // pitch of recv/send per candidate
     int c_cap;        // pitch of C per candidate, multiple of 256
+    // ---- class table (rollout only).  The particle-encoder chain depends only on [attrs, phys, action]: for an object
+    // particle that row is the same for every candidate and every rollout step (action is zero for objects,
+    // forward_dynamics.py:87-88; phys is broadcast, :151), for a tool particle it changes per look-ahead step.
+    // So p_enc / P / U0 / V0 live in a small table: rows [0,N_o) valid object i, [N_o,2N_o) masked-out object i,
+    // 2N_o + b*M + m tool m of candidate b.  cls_on = 0: plain per-(b,i) rows (ag_forward).
+    int cls_on, N_o, M;
+    const uint8_t* vmask;                  // (B,N) validity, selects the object variant
+    float* c_node_in;                      // (2N_o + B*M, NODE_IN)
+    float* c_eff; float* c_P; float* c_U; float* c_V;   // (2N_o + B*M, NFP)
 };
-hipError_t launch_node_enc(const float* wblob, const GraphBufs& g, hipStream_t st);
+inline long cls_rows(int N_o, int M, int B) { return 2L * N_o + (long)B * M; }
+// row0/nrows select a slice of the class table when g.cls_on, else all B*N rows are encoded
+hipError_t launch_node_enc(const float* wblob, const GraphBufs& g, long row0, long nrows, hipStream_t st);
 hipError_t launch_edge_enc(const float* wblob, const GraphBufs& g, hipStream_t st);
-hipError_t launch_mp(const GraphBufs& g, hipStream_t st);
-hipError_t launch_node_prop(const float* wblob, const GraphBufs& g, hipStream_t st);
-hipError_t launch_node_final(const float* wblob, const GraphBufs& g, float clamp, float* pred_pos, float* pred_motion,
-                             hipStream_t st);
+// first_round: U/V/eff of the round come from the class table (when g.cls_on)
+hipError_t launch_mp(const GraphBufs& g, int first_round, hipStream_t st);
+hipError_t launch_node_prop(const float* wblob, const GraphBufs& g, int first_round, hipStream_t st);
+hipError_t launch_node_final(const float* wblob, const GraphBufs& g, int first_round, float clamp, float* pred_pos,
+                             float* pred_motion, hipStream_t st);
 
 // model-input preparation for ag_forward: state (B,n_his,N,3) etc. -> node_in, feat12
 hipError_t launch_prep(const float* state, const float* attrs, const float* action, const float* phys,
@@ -115,6 +127,7 @@ struct RollBufs {
 struct RollArgs {
     int B, N_o, M, H, li, ai, y_mode, b0;  // b0 = first candidate of this chunk in the full batch
     float grip; int grip_on; float phys;
+    int write_obj_cls;                        // roll_init also writes the object rows of the class table
     const float* phys_vec;                    // null or (N_o,) per-particle physics parameter
     const float* state0; int state0_batched;  // (N_o,3) or (Bfull,N_o,3)
     const uint8_t* obj_mask;                  // (Bfull,N_o) or null

@@ -19,8 +19,14 @@ struct MpDev {
     const float* C; const float* U; const float* V; float* agg;
     const int* send; const int* row_ptr;
     int B, N, edge_cap, c_cap;
+    int cls; int N_o, M; const uint8_t* vmask;   // cls: U/V rows come from the class table (round 0 of a rollout)
 };
+__device__ __forceinline__ long mp_cls_row(const MpDev& g, int b, int i) {
+    if (i >= g.N_o) return 2L * g.N_o + (long)b * g.M + (i - g.N_o);
+    return g.vmask[(long)b * g.N + i] ? i : g.N_o + i;
+}
 // <= 64 VGPRs (8 waves/SIMD bound) so that one k_mp wavefront fits on a SIMD beside two MLP-chain wavefronts
+template <bool CLS>
 __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * MP_WAVES + (threadIdx.x >> 6);
@@ -28,37 +34,44 @@ __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
     const int b = (int)(row / g.N), i = (int)(row - (long)b * g.N);
     const int e0 = g.row_ptr[(long)b * (g.N + 1) + i], e1 = g.row_ptr[(long)b * (g.N + 1) + i + 1];
     if (lane >= NFP / 4) return;
-    const f32x4 u = reinterpret_cast<const f32x4*>(g.U + row * NFP)[lane];
+    const f32x4 u = reinterpret_cast<const f32x4*>(g.U + (CLS ? mp_cls_row(g, b, i) : row) * NFP)[lane];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int* snd = g.send + (long)b * g.edge_cap;
     const float* Cb = g.C + (long)b * g.c_cap * NFP;
-    const float* Vb = g.V + (long)b * g.N * NFP;
+    const float* Vb = CLS ? g.V : g.V + (long)b * g.N * NFP;
     int e = e0;
-    for (; e + 4 <= e1; e += 4) {                            // 8 independent 16-B loads in flight per lane
-        f32x4 c[4], v[4];
+    constexpr int UNR = CLS ? 2 : 4;                         // class-table rows are L2 hits: less to hide, fewer VGPRs
+    for (; e + UNR <= e1; e += UNR) {                        // 2*UNR independent 16-B loads in flight per lane
+        f32x4 c[UNR], v[UNR];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < UNR; ++k) {
+            const int sj = snd[e + k];
             c[k] = reinterpret_cast<const f32x4*>(Cb + (long)(e + k) * NFP)[lane];
-            v[k] = reinterpret_cast<const f32x4*>(Vb + (long)snd[e + k] * NFP)[lane];
+            v[k] = reinterpret_cast<const f32x4*>(Vb + (CLS ? mp_cls_row(g, b, sj) : (long)sj) * NFP)[lane];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < UNR; ++k)
 #pragma unroll
             for (int d = 0; d < 4; ++d) acc[d] += fmaxf((c[k][d] + u[d]) + v[k][d], 0.0f);
     }
     for (; e < e1; ++e) {
         const f32x4 c = reinterpret_cast<const f32x4*>(Cb + (long)e * NFP)[lane];
-        const f32x4 v = reinterpret_cast<const f32x4*>(Vb + (long)snd[e] * NFP)[lane];
+        const int sj = snd[e];
+        const f32x4 v = reinterpret_cast<const f32x4*>(Vb + (CLS ? mp_cls_row(g, b, sj) : (long)sj) * NFP)[lane];
 #pragma unroll
         for (int d = 0; d < 4; ++d) acc[d] += fmaxf((c[d] + u[d]) + v[d], 0.0f);
     }
     reinterpret_cast<f32x4*>(g.agg + row * NFP)[lane] = acc;
 }
 
-hipError_t launch_mp(const GraphBufs& g, hipStream_t st) {
-    MpDev d{g.C, g.U, g.V, g.agg, g.send, g.row_ptr, g.B, g.N, g.edge_cap, g.c_cap};
+hipError_t launch_mp(const GraphBufs& g, int first_round, hipStream_t st) {
+    const int cls = g.cls_on && first_round;
+    MpDev d{g.C, cls ? g.c_U : g.U, cls ? g.c_V : g.V, g.agg, g.send, g.row_ptr, g.B, g.N, g.edge_cap, g.c_cap,
+            cls, g.N_o, g.M, g.vmask};
     const long rows = (long)g.B * g.N;
-    hipLaunchKernelGGL(k_mp, dim3((unsigned)((rows + MP_WAVES - 1) / MP_WAVES)), dim3(MP_WAVES * 64), 0, st, d);
+    const dim3 grid((unsigned)((rows + MP_WAVES - 1) / MP_WAVES));
+    if (cls) hipLaunchKernelGGL(k_mp<true>, grid, dim3(MP_WAVES * 64), 0, st, d);
+    else hipLaunchKernelGGL(k_mp<false>, grid, dim3(MP_WAVES * 64), 0, st, d);
     return hipGetLastError();
 }
 
@@ -103,6 +116,7 @@ struct RollDev {
     RollArgs a;
     float* hist; float* pred; uint8_t* mask; uint8_t* tool;
     float* node_in; float* feat12; float* group; int n_inst;
+    float* c_node_in; int write_obj_cls;   // class-table inputs (GraphBufs): tool rows every init, object rows on demand
 };
 constexpr int RT = 256;
 
@@ -195,6 +209,19 @@ __global__ __launch_bounds__(RT) void k_roll_init(RollDev d) {
         for (int k = 0; k < d.n_inst; ++k) d.group[row * d.n_inst + k] = (k == 0 && !is_tool && i < count) ? 1.0f : 0.0f;
         d.mask[row] = (is_tool || ov) ? 1 : 0;               // state_mask (:107-109 / :302-304)
         d.tool[row] = is_tool ? 1 : 0;                       // eef_mask (:111-112)
+        if (d.c_node_in) {                                   // class-table inputs (see GraphBufs)
+            if (is_tool) {
+                float* cn = d.c_node_in + (2L * a.N_o + (long)b * a.M + (i - a.N_o)) * NODE_IN;
+#pragma unroll
+                for (int k = 0; k < NODE_IN; ++k) cn[k] = n[k];
+            } else if (d.write_obj_cls && b == 0) {          // same for every candidate: candidate 0 writes both variants
+                float* cv = d.c_node_in + (long)i * NODE_IN;
+                float* ci = d.c_node_in + ((long)a.N_o + i) * NODE_IN;
+                cv[0] = 1.0f; ci[0] = 0.0f;
+#pragma unroll
+                for (int k = 1; k < NODE_IN; ++k) { cv[k] = n[k]; ci[k] = n[k]; }
+            }
+        }
     }
 }
 
@@ -254,6 +281,7 @@ static RollDev to_dev(const RollArgs& a, const RollBufs& r, const GraphBufs& g) 
     RollDev d;
     d.a = a; d.hist = r.hist; d.pred = r.pred; d.mask = r.mask; d.tool = r.tool;
     d.node_in = g.node_in; d.feat12 = g.feat12; d.group = g.group; d.n_inst = g.n_inst;
+    d.c_node_in = g.cls_on ? g.c_node_in : nullptr; d.write_obj_cls = a.write_obj_cls;
     return d;
 }
 hipError_t launch_roll_init(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st) {

@@ -237,10 +237,19 @@ struct GDev {
     const int* recv; const int* send; const int* row_ptr; const int* n_edges;
     int B, N, n_p, n_inst, edge_cap, c_cap;
     float clamp; float* pred_pos; float* pred_motion;
+    int cls_on, N_o, M, first_round; const uint8_t* vmask;
+    const float* c_eff; const float* c_P;
+    long row0, nrows;          // k_node_enc: slice of rows to encode
     unsigned long long* dbg;   // diagnostic build of the clock probe only: 4 stamps per workgroup, never read by kernels
 };
 
 using WL = WeightLayout;
+
+// class-table row of particle i of candidate b (see GraphBufs)
+__device__ __forceinline__ long cls_row(const GDev& g, int b, int i) {
+    if (i >= g.N_o) return 2L * g.N_o + (long)b * g.M + (i - g.N_o);
+    return g.vmask[(long)b * g.N + i] ? i : g.N_o + i;
+}
 
 // ------------------------------------------------------------------------------------------------ edge chain
 // rel_inputs (17) -> Encoder(17,150,150) -> W1*enc + b_rp  => C      (model.py:249-282, 303, 317-318 first block)
@@ -310,10 +319,10 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
 __global__ __launch_bounds__(WG, 2) void k_node_enc(GDev g) {
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long nrows = (long)g.B * g.N;
-    const long row = (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
-    const bool valid = row < nrows;
-    const long rowc = valid ? row : nrows - 1;
+    const long rend = g.row0 + g.nrows;
+    const long row = g.row0 + (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
+    const bool valid = row < rend;
+    const long rowc = valid ? row : rend - 1;
 
     stage_now<NODE_L1_CHUNKS * CHUNK_FLOATS_MB5>(lds + BUF_FLOATS, g.w + WL::N_L1, tid);
     Stager<Q_FLOATS> sn;
@@ -366,9 +375,12 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     // x (the agg tile) is dead: reuse its 80 registers as the landing zone, one operand at a time.  Left to itself
     // the compiler issues both 80-register row loads up front on top of the live accumulators and spills ~80 VGPRs;
     // an opaque zero added to the row index, data-dependent on the accumulator, pins each load group in place.
-    load_rows(x, g.P, rowc + pin_after(y), lane);
+    const int pb = (int)(rowc / g.N), pi = (int)(rowc - (long)pb * g.N);
+    const long crow = g.cls_on ? cls_row(g, pb, pi) : rowc;
+    load_rows(x, g.cls_on ? g.c_P : g.P, crow + pin_after(y), lane);
     add_act(y, x);
-    load_rows(x, g.eff, rowc + pin_after(y), lane);
+    const bool ceff = g.cls_on && g.first_round;             // round 1: the previous effect is p_enc itself
+    load_rows(x, ceff ? g.c_eff : g.eff, (ceff ? crow : rowc) + pin_after(y), lane);
     add_act(y, x);
     relu_one(y, lane);                                       // y = new particle effect (slot 150 forced to 1)
     if (!LAST) {
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
         for (int r = 0; r < 16; ++r) m[0][r] = 0.0f;
         mma_act<0, KCH, 1>(lds, y, m, lane);
         // motion xyz = output features 0,1,2 = registers 0,1,2 of lanes 0..31
-        const int b = (int)(rowc / g.N), i = (int)(rowc - (long)b * g.N);
+        const int b = pb, i = pi;
         if (valid && lane < 32 && i < g.n_p) {
             const float* cur = g.feat12 + rowc * F12 + 9;    // state[:, -1]  (model.py:338)
             const long o = ((long)b * g.n_p + i) * 3;
@@ -408,6 +420,8 @@ static GDev to_dev(const float* w, const GraphBufs& g) {
     d.V = g.V; d.agg = g.agg; d.C = g.C; d.recv = g.recv; d.send = g.send; d.row_ptr = g.row_ptr;
     d.n_edges = g.n_edges; d.B = g.B; d.N = g.N; d.n_p = g.n_p; d.n_inst = g.n_inst; d.edge_cap = g.edge_cap;
     d.c_cap = g.c_cap; d.clamp = 0; d.pred_pos = nullptr; d.pred_motion = nullptr;
+    d.cls_on = g.cls_on; d.N_o = g.N_o; d.M = g.M; d.first_round = 0; d.vmask = g.vmask; d.c_eff = g.c_eff; d.c_P = g.c_P;
+    d.row0 = 0; d.nrows = (long)g.B * g.N;
     d.dbg = nullptr;
     return d;
 }
@@ -444,17 +458,26 @@ hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
     }
     return hipGetLastError();
 }
-hipError_t launch_node_enc(const float* w, const GraphBufs& g, hipStream_t st) {
-    hipLaunchKernelGGL(k_node_enc, dim3(node_grid(g)), dim3(WG), 0, st, to_dev(w, g));
-    return hipGetLastError();
-}
-hipError_t launch_node_prop(const float* w, const GraphBufs& g, hipStream_t st) {
-    hipLaunchKernelGGL(k_node_prop<false>, dim3(node_grid(g)), dim3(WG), 0, st, to_dev(w, g));
-    return hipGetLastError();
-}
-hipError_t launch_node_final(const float* w, const GraphBufs& g, float clamp, float* pred_pos, float* pred_motion,
-                             hipStream_t st) {
+hipError_t launch_node_enc(const float* w, const GraphBufs& g, long row0, long nrows, hipStream_t st) {
     GDev d = to_dev(w, g);
+    if (g.cls_on) {   // encode a slice of the class table instead of all B*N rows
+        d.node_in = g.c_node_in; d.eff = g.c_eff; d.P = g.c_P; d.U = g.c_U; d.V = g.c_V;
+        d.row0 = row0; d.nrows = nrows;
+    }
+    if (d.nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_node_enc, dim3((unsigned)((d.nrows + WG_ROWS - 1) / WG_ROWS)), dim3(WG), 0, st, d);
+    return hipGetLastError();
+}
+hipError_t launch_node_prop(const float* w, const GraphBufs& g, int first_round, hipStream_t st) {
+    GDev d = to_dev(w, g);
+    d.first_round = first_round;
+    hipLaunchKernelGGL(k_node_prop<false>, dim3(node_grid(g)), dim3(WG), 0, st, d);
+    return hipGetLastError();
+}
+hipError_t launch_node_final(const float* w, const GraphBufs& g, int first_round, float clamp, float* pred_pos,
+                             float* pred_motion, hipStream_t st) {
+    GDev d = to_dev(w, g);
+    d.first_round = first_round;
     d.clamp = clamp; d.pred_pos = pred_pos; d.pred_motion = pred_motion;
     hipLaunchKernelGGL(k_node_prop<true>, dim3(node_grid(g)), dim3(WG), 0, st, d);
     return hipGetLastError();
