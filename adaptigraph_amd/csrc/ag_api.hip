@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -48,6 +49,7 @@ struct ag_ctx {
     int* d_repeat = nullptr; size_t repeat_cap = 0;
     std::vector<int> h_repeat;   // ctx-owned copy so the caller's array may die right after the call
     int* d_overflow = nullptr;
+    float* d_cself = nullptr;    // (256, NFP): rows 0/1 = C of an object / tool self-loop edge (see GraphBufs)
     // second in-library stream: alternate chunks run on it so that the HBM-bound kernels of one chunk overlap the
     // MFMA-bound chains of the other (fork/join with events around every rollout call)
     static constexpr int kMaxStreams = 4;
@@ -146,6 +148,7 @@ struct Work {
     RollBufs r{};
     int* ell; int* deg; int* slice_tot; int* cta_flag;
     int* recv; int* send; int* row_ptr; int* n_edges;
+    int* ns_edge; int* n_ns;
 };
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
@@ -166,7 +169,7 @@ size_t work_bytes(int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices
     const size_t rows = (size_t)Bc * N;
     size_t bytes = 16 * 256;
     bytes += rows * (NODE_IN + F12 + (own_group ? n_inst : 0)) * 4 + 5 * rows * NFP * 4 + (size_t)Bc * c_cap * NFP * 4;
-    if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 2) * 4 + 2 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
+    if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 3) * 4 + 3 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
     if (roll) bytes += (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
                        (size_t)cls_rows(N_o, N - N_o, Bc) * (NODE_IN + 4 * NFP) * 4;
     return bytes + 64 * 256;
@@ -196,6 +199,8 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
         w.send = s.take<int>((size_t)Bc * edge_cap);
         w.row_ptr = s.take<int>((size_t)Bc * (N + 1));
         w.n_edges = s.take<int>(Bc);
+        w.ns_edge = s.take<int>((size_t)Bc * edge_cap);
+        w.n_ns = s.take<int>(Bc);
         w.g.recv = w.recv; w.g.send = w.send; w.g.row_ptr = w.row_ptr; w.g.n_edges = w.n_edges;
     }
     if (roll) {
@@ -289,6 +294,7 @@ int ag_ctx_destroy(ag_ctx* c) {
     }
     if (c->d_w) (void)hipFree(c->d_w);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
+    if (c->d_cself) (void)hipFree(c->d_cself);
     if (c->d_repeat) (void)hipFree(c->d_repeat);
     if (c->slab.base) (void)hipFree(c->slab.base);
     delete c;
@@ -328,6 +334,31 @@ int ag_ctx_load_weights(ag_ctx* c, const float* const* t, int32_t n) {
     pack_layer(b + WL::P_P2, t[20], NF, 0, 3, NF, t[21], 1);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(c->d_w, b, blob.size() * 4, hipMemcpyHostToDevice));
+    // C rows of the two kinds of self-loop edge (object: attrs 1,0; tool: attrs 0,1), through the real edge chain on
+    // a 2-particle, 2-edge graph {(0,0),(1,1)} - bitwise what k_edge_enc would produce for any such edge.
+    {
+        if (!c->d_cself) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_cself), 256 * NFP * 4));
+        struct Mini { float node_in[2 * NODE_IN]; float feat12[2 * F12]; float group[2]; int recv[2]; int send[2]; int n_edges; int pad; } h{};
+        h.node_in[0] = 1.f; h.node_in[6] = 1.f;                         // object particle
+        h.node_in[NODE_IN + 1] = 1.f; h.node_in[NODE_IN + 6] = 1.f;     // tool particle
+        h.group[0] = 1.f;
+        h.recv[0] = 0; h.recv[1] = 1; h.send[0] = 0; h.send[1] = 1; h.n_edges = 2;
+        char* d = nullptr;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), sizeof(Mini)));
+        HIPCHK(c, hipMemcpy(d, &h, sizeof(Mini), hipMemcpyHostToDevice));
+        GraphBufs g{};
+        g.node_in = reinterpret_cast<float*>(d + offsetof(Mini, node_in));
+        g.feat12 = reinterpret_cast<float*>(d + offsetof(Mini, feat12));
+        g.group = reinterpret_cast<float*>(d + offsetof(Mini, group));
+        g.recv = reinterpret_cast<int*>(d + offsetof(Mini, recv));
+        g.send = reinterpret_cast<int*>(d + offsetof(Mini, send));
+        g.n_edges = reinterpret_cast<int*>(d + offsetof(Mini, n_edges));
+        g.C = c->d_cself; g.B = 1; g.N = 2; g.n_p = 1; g.n_inst = 1; g.edge_cap = 2; g.c_cap = 256;
+        hipError_t e = launch_edge_enc(c->d_w, g, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        (void)hipFree(d);
+        if (e != hipSuccess) return fail(c, AG_ERR_HIP, "self-loop C rows: %s", hipGetErrorString(e));
+    }
     c->have_w = true;
     return AG_OK;
 }
@@ -441,7 +472,7 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     const size_t wb = work_bytes(Bc, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
     rc = ensure_slab(c, wb * ns);
     if (rc) return rc;
-    Work ws[ag_ctx::kMaxStreams];
+    Work ws[ag_ctx::kMaxStreams] = {};
     for (int i = 0; i < ns; ++i) {
         rc = carve_work(c, ws[i], Bc, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
         if (rc) return rc;
@@ -469,6 +500,8 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         c->prof_stream = cs;
         GraphBufs g = w.g;
         g.B = nb; g.n_p = p->N_o;
+        static const bool dedupe = !(getenv("AG_NO_SELF_DEDUPE") && atoi(getenv("AG_NO_SELF_DEDUPE")));
+        if (dedupe) { g.c_self = c->d_cself; g.ns_edge = w.ns_edge; g.n_ns = w.n_ns; }
         RollArgs ra{};
         ra.B = nb; ra.N_o = p->N_o; ra.M = p->M; ra.H = p->H; ra.y_mode = p->y_mode; ra.b0 = b0;
         ra.grip = p->gripper_offset; ra.grip_on = p->gripper_enable; ra.phys = p->physics_param; ra.phys_vec = d_phys_vec;
@@ -496,6 +529,7 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
             obj_cls_ready[ci % ns] = true;
             for (int ai = 1; ai <= max_rep; ++ai) {           // forward_dynamics.py:156
                 HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));
+                if (g.ns_edge) { Scoped s(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, nb, N, edge_cap, w.ns_edge, w.n_ns, cs)); }
                 rc = run_model(c, g, w.r.pred, w.r.motion, cs);
                 if (rc) return rc;
                 ra.ai = ai;

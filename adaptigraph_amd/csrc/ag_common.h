@@ -80,6 +80,9 @@ struct EdgeArgs {
     int zero_on_overflow;       // internal rollout use: present an EMPTY graph downstream when E > edge_cap
 };
 hipError_t launch_edge_build(const EdgeArgs& a, hipStream_t st, void (*mark)(void*, int, int), void* mark_ctx);
+// list of non-self-loop edges per candidate (self-loop dedupe, see GraphBufs)
+hipError_t launch_edge_nonself(const int* recv, const int* send, const int* row_ptr, int B, int N, int edge_cap,
+                               int* ns_edge, int* n_ns, hipStream_t st);
 
 struct GraphBufs {
     // per-chunk activations; node rows = b*N + i, edge rows = b*c_cap + e, pitch NFP floats
@@ -102,6 +105,12 @@ struct GraphBufs {
     const uint8_t* vmask;                  // (B,N) validity, selects the object variant
     float* c_node_in;                      // (2N_o + B*M, NODE_IN)
     float* c_eff; float* c_P; float* c_U; float* c_V;   // (2N_o + B*M, NFP)
+    // ---- self-loop dedupe (rollout only).  A self-loop edge (i,i) has relation input [attrs_i, attrs_i, 0, 0..0]
+    // (group and position differences of a particle with itself are exactly 0), so its C row is one of two
+    // constants of the model: c_self[0] for an object particle (attrs 1,0), c_self[1] for a tool (attrs 0,1).
+    // ns_edge lists the edges that are NOT self-loops; only those go through the relation encoder.
+    const float* c_self;                   // (2, NFP) or null
+    const int* ns_edge; const int* n_ns;   // (B,edge_cap), (B,) or null
 };
 inline long cls_rows(int N_o, int M, int B) { return 2L * N_o + (long)B * M; }
 // row0/nrows select a slice of the class table when g.cls_on, else all B*N rows are encoded

@@ -513,6 +513,48 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     return hipGetLastError();
 }
 
+// ---- non-self-loop edge list (self-loop dedupe).  One workgroup per candidate.  Row i has at most one self-loop;
+// S(i) = number of self-loops in rows < i (integer scan); the t-th non-self edge keeps the CSR order.
+__global__ __launch_bounds__(EW) void k_edge_nonself(const int* __restrict__ send_all, const int* __restrict__ row_ptr_all,
+                                                      int N, int edge_cap, int* __restrict__ ns_all, int* __restrict__ n_ns) {
+    __shared__ int scan[EW];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int* send = send_all + (long)b * edge_cap;
+    const int* rp = row_ptr_all + (long)b * (N + 1);
+    int* ns = ns_all + (long)b * edge_cap;
+    const int per = (N + EW - 1) / EW;
+    const int i0 = min(N, tid * per), i1 = min(N, i0 + per);
+    int mine = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int e0 = rp[i], e1 = rp[i + 1];
+        for (int e = e0; e < e1; ++e) mine += send[e] == i ? 1 : 0;
+    }
+    scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < EW; off <<= 1) {
+        int v = 0;
+        if (tid >= off) v = scan[tid - off];
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    int S = scan[tid] - mine;                              // self-loops before my first row
+    for (int i = i0; i < i1; ++i) {
+        const int e0 = rp[i], e1 = rp[i + 1];
+        for (int e = e0; e < e1; ++e) {
+            if (send[e] == i) ++S;
+            else ns[e - S] = e;
+        }
+    }
+    if (tid == EW - 1) n_ns[b] = rp[N] - scan[EW - 1];
+}
+hipError_t launch_edge_nonself(const int* recv, const int* send, const int* row_ptr, int B, int N, int edge_cap,
+                               int* ns_edge, int* n_ns, hipStream_t st) {
+    (void)recv;
+    hipLaunchKernelGGL(k_edge_nonself, dim3(B), dim3(EW), 0, st, send, row_ptr, N, edge_cap, ns_edge, n_ns);
+    return hipGetLastError();
+}
+
 size_t edge_build_max_particles() { return MAXCH * 64; }
 // ints of ELL scratch per (candidate, particle)
 int edge_ell_stride(int N, int topk) { return topk < N ? topk : 0; }

@@ -20,6 +20,7 @@ struct MpDev {
     const int* send; const int* row_ptr;
     int B, N, edge_cap, c_cap;
     int cls; int N_o, M; const uint8_t* vmask;   // cls: U/V rows come from the class table (round 0 of a rollout)
+    const float* c_self;                         // self-loop dedupe: C row of a self-loop edge (null = off)
 };
 __device__ __forceinline__ long mp_cls_row(const MpDev& g, int b, int i) {
     if (i >= g.N_o) return 2L * g.N_o + (long)b * g.M + (i - g.N_o);
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
             const int sj = snd[e + k];
-            c[k] = reinterpret_cast<const f32x4*>(Cb + (long)(e + k) * NFP)[lane];
+            const float* cr = (g.c_self && sj == i) ? g.c_self + (i >= g.N_o ? NFP : 0) : Cb + (long)(e + k) * NFP;
+            c[k] = reinterpret_cast<const f32x4*>(cr)[lane];
             v[k] = reinterpret_cast<const f32x4*>(Vb + (CLS ? mp_cls_row(g, b, sj) : (long)sj) * NFP)[lane];
         }
 #pragma unroll
@@ -55,8 +57,9 @@ __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
             for (int d = 0; d < 4; ++d) acc[d] += fmaxf((c[k][d] + u[d]) + v[k][d], 0.0f);
     }
     for (; e < e1; ++e) {
-        const f32x4 c = reinterpret_cast<const f32x4*>(Cb + (long)e * NFP)[lane];
         const int sj = snd[e];
+        const float* cr = (g.c_self && sj == i) ? g.c_self + (i >= g.N_o ? NFP : 0) : Cb + (long)e * NFP;
+        const f32x4 c = reinterpret_cast<const f32x4*>(cr)[lane];
         const f32x4 v = reinterpret_cast<const f32x4*>(Vb + (CLS ? mp_cls_row(g, b, sj) : (long)sj) * NFP)[lane];
 #pragma unroll
         for (int d = 0; d < 4; ++d) acc[d] += fmaxf((c[d] + u[d]) + v[d], 0.0f);
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
 hipError_t launch_mp(const GraphBufs& g, int first_round, hipStream_t st) {
     const int cls = g.cls_on && first_round;
     MpDev d{g.C, cls ? g.c_U : g.U, cls ? g.c_V : g.V, g.agg, g.send, g.row_ptr, g.B, g.N, g.edge_cap, g.c_cap,
-            cls, g.N_o, g.M, g.vmask};
+            cls, g.N_o, g.M, g.vmask, g.c_self};
     const long rows = (long)g.B * g.N;
     const dim3 grid((unsigned)((rows + MP_WAVES - 1) / MP_WAVES));
     if (cls) hipLaunchKernelGGL(k_mp<true>, grid, dim3(MP_WAVES * 64), 0, st, d);

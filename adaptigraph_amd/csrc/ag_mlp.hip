@@ -240,6 +240,7 @@ struct GDev {
     int cls_on, N_o, M, first_round; const uint8_t* vmask;
     const float* c_eff; const float* c_P;
     long row0, nrows;          // k_node_enc: slice of rows to encode
+    const int* ns_edge; const int* n_ns;   // k_edge_enc: non-self-loop edge list (null = every edge)
     unsigned long long* dbg;   // diagnostic build of the clock probe only: 4 stamps per workgroup, never read by kernels
 };
 
@@ -256,10 +257,13 @@ __device__ __forceinline__ long cls_row(const GDev& g, int b, int i) {
 __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long wg_row0 = (long)blockIdx.x * WG_ROWS;
-    const int b = (int)(wg_row0 / g.c_cap);
-    const int e0 = (int)(wg_row0 - (long)b * g.c_cap);
-    const int ne = g.n_edges[b];
+    // tile-major: block = tile * B + candidate.  Workgroups are dealt to XCDs / shader engines in a fixed rotation;
+    // with candidate-major order every candidate's early-exit tail (tiles past its edge count) lands on the same
+    // engines and the others carry all the work (measured: 16.7 % fewer rows, same kernel time).  Tile-major puts
+    // every early-exit workgroup at the end of the grid.
+    const int b = (int)(blockIdx.x % (unsigned)g.B);
+    const int e0 = (int)(blockIdx.x / (unsigned)g.B) * WG_ROWS;
+    const int ne = g.n_ns ? g.n_ns[b] : g.n_edges[b];       // rows to encode: all edges, or the non-self-loop ones
     if (e0 >= ne) return;                                    // whole workgroup past this candidate's edges
     if (g.dbg && tid == 0) {
         g.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
@@ -271,9 +275,10 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
     Stager<Q_FLOATS> sn;
     sn.load(g.w + WL::E_L2, tid);
 
-    const int el = e0 + wave * 32 + (lane & 31);
-    const bool valid = el < ne;
-    const int elc = valid ? el : 0;
+    const int t = e0 + wave * 32 + (lane & 31);
+    const bool valid = t < ne;
+    const int el = g.ns_edge ? g.ns_edge[(long)b * g.edge_cap + (valid ? t : 0)] : t;   // edge id (C row) of this lane
+    const int elc = valid ? el : (g.ns_edge ? el : 0);
     const int r = g.recv[(long)b * g.edge_cap + elc], s = g.send[(long)b * g.edge_cap + elc];
     const long pr = (long)b * g.N + r, ps = (long)b * g.N + s;
     float f[8 * EDGE_L1_CHUNKS];
@@ -422,6 +427,7 @@ static GDev to_dev(const float* w, const GraphBufs& g) {
     d.c_cap = g.c_cap; d.clamp = 0; d.pred_pos = nullptr; d.pred_motion = nullptr;
     d.cls_on = g.cls_on; d.N_o = g.N_o; d.M = g.M; d.first_round = 0; d.vmask = g.vmask; d.c_eff = g.c_eff; d.c_P = g.c_P;
     d.row0 = 0; d.nrows = (long)g.B * g.N;
+    d.ns_edge = g.ns_edge; d.n_ns = g.n_ns;
     d.dbg = nullptr;
     return d;
 }

@@ -187,10 +187,14 @@ def main():
         tool[:, N_o:] = True
         pos = torch.cat([state0, torch.tensor([[float(a_local[0, 0, 0]), float(state0[:, 1].min()) + 0.1,
                                                 float(a_local[0, 0, 1])]], device=dev)])[None]
-        E = int(ag.construct_edges_index(pos, task["adj_thresh"], mask, tool, task["topk"], True).n_edges[0])
+        el0 = ag.construct_edges_index(pos, task["adj_thresh"], mask, tool, task["topk"], True)
+        E = int(el0.n_edges[0])
+        # self-loop edges are not run through the relation encoder (their C row is a model constant): count the FLOPs
+        # of the edges the kernel actually encodes
+        E_enc = E - int((el0.recv[0, :E] == el0.send[0, :E]).sum())
         total_steps = B * H * R
         launches_per_step = max(1, n_edge // prof_steps)
-        edges_per_launch = E * (hi - lo) * H * R / launches_per_step
+        edges_per_launch = E_enc * (hi - lo) * H * R / launches_per_step
         avg_ms = ms_edge / max(1, n_edge)
         traffic = None                                                 # PMC bytes per launch, measured off-line
         tpath = os.path.join(ROOT, "profiles", "r01_traffic_k_edge_enc.json")
@@ -205,7 +209,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: cloth, 1024 candidates x 20 rollout steps (2 look-ahead x "
                                    "repeat 10) x 2025+1 particles, radius graph rebuilt every step",
-                       "candidates": B, "horizon": H * R, "particles": N_o + 1, "edges_per_graph": E,
+                       "candidates": B, "horizon": H * R, "particles": N_o + 1, "edges_per_graph": E, "edges_encoded_per_graph": E_enc,
                        "parallelism": f"candidates sharded over {world} GPU(s), all-gather of costs",
                        "ms_per_mpc_rollout": dt / args.steps * 1e3},
             "roofline": {"bound": "mfma", "kernel": "k_edge_enc", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
