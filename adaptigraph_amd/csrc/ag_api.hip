@@ -168,7 +168,7 @@ size_t work_bytes(int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices
                   bool own_group, int N_o, int ell_stride) {
     const size_t rows = (size_t)Bc * N;
     size_t bytes = 16 * 256;
-    bytes += rows * (NODE_IN + F12 + (own_group ? n_inst : 0)) * 4 + 5 * rows * NFP * 4 + (size_t)Bc * c_cap * NFP * 4;
+    bytes += rows * (NODE_IN + F12 + (own_group ? n_inst : 0)) * 4 + 5 * rows * NFP * 4 + ((size_t)Bc * c_cap + 256) * NFP * 4;
     if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 3) * 4 + 3 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
     if (roll) bytes += (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
                        (size_t)cls_rows(N_o, N - N_o, Bc) * (NODE_IN + 4 * NFP) * 4;
@@ -188,7 +188,7 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
     w.g.U = s.take<float>(rows * NFP);
     w.g.V = s.take<float>(rows * NFP);
     w.g.agg = s.take<float>(rows * NFP);
-    w.g.C = s.take<float>((size_t)Bc * c_cap * NFP);
+    w.g.C = s.take<float>(((size_t)Bc * c_cap + 256) * NFP);   // + room for the two self-loop constant rows
     w.g.B = Bc; w.g.N = N; w.g.n_inst = n_inst; w.g.edge_cap = edge_cap; w.g.c_cap = c_cap; w.g.n_p = N_o;
     if (own_edges) {
         w.ell = s.take<int>(rows * (size_t)std::max(1, ell_stride));
@@ -501,7 +501,11 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         GraphBufs g = w.g;
         g.B = nb; g.n_p = p->N_o;
         static const bool dedupe = !(getenv("AG_NO_SELF_DEDUPE") && atoi(getenv("AG_NO_SELF_DEDUPE")));
-        if (dedupe) { g.c_self = c->d_cself; g.ns_edge = w.ns_edge; g.n_ns = w.n_ns; }
+        if (dedupe) {
+            g.c_self = c->d_cself; g.ns_edge = w.ns_edge; g.n_ns = w.n_ns;
+            g.self_row = (long)Bc * edge_cap;     // behind the last candidate's C rows of this workspace
+            HIPCHK(c, hipMemcpyAsync(w.g.C + (size_t)g.self_row * NFP, c->d_cself, 2 * NFP * 4, hipMemcpyDeviceToDevice, cs));
+        }
         RollArgs ra{};
         ra.B = nb; ra.N_o = p->N_o; ra.M = p->M; ra.H = p->H; ra.y_mode = p->y_mode; ra.b0 = b0;
         ra.grip = p->gripper_offset; ra.grip_on = p->gripper_enable; ra.phys = p->physics_param; ra.phys_vec = d_phys_vec;

@@ -110,6 +110,7 @@ struct GraphBufs {
     // constants of the model: c_self[0] for an object particle (attrs 1,0), c_self[1] for a tool (attrs 0,1).
     // ns_edge lists the edges that are NOT self-loops; only those go through the relation encoder.
     const float* c_self;                   // (2, NFP) or null
+    long self_row;                         // row of C where c_self[0..1] were copied (k_mp reads them from there)
     const int* ns_edge; const int* n_ns;   // (B,edge_cap), (B,) or null
 };
 inline long cls_rows(int N_o, int M, int B) { return 2L * N_o + (long)B * M; }

@@ -20,12 +20,12 @@ struct MpDev {
     const int* send; const int* row_ptr;
     int B, N, edge_cap, c_cap;
     int cls; int N_o, M; const uint8_t* vmask;   // cls: U/V rows come from the class table (round 0 of a rollout)
-    const float* c_self;                         // self-loop dedupe: C row of a self-loop edge (null = off)
+    int dedupe; unsigned self_row;               // self-loop dedupe: C rows self_row / self_row+1 hold the object /
+                                                 // tool self-loop constants (appended to the C buffer)
 };
-__device__ __forceinline__ long mp_cls_row(const MpDev& g, int b, int i) {
-    if (i >= g.N_o) return 2L * g.N_o + (long)b * g.M + (i - g.N_o);
-    return g.vmask[(long)b * g.N + i] ? i : g.N_o + i;
-}
+// Class-table rows (round 0 of a rollout): a particle that takes part in an edge is valid by construction (masked
+// pairs never pass the radius test, graph.py:253-256), so its row is a pure function of its index; a receiver
+// without edges gets agg = 0 whatever its U row is.
 // <= 64 VGPRs (8 waves/SIMD bound) so that one k_mp wavefront fits on a SIMD beside two MLP-chain wavefronts
 template <bool CLS>
 __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
@@ -35,21 +35,29 @@ __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
     const int b = (int)(row / g.N), i = (int)(row - (long)b * g.N);
     const int e0 = g.row_ptr[(long)b * (g.N + 1) + i], e1 = g.row_ptr[(long)b * (g.N + 1) + i + 1];
     if (lane >= NFP / 4) return;
-    const f32x4 u = reinterpret_cast<const f32x4*>(g.U + (CLS ? mp_cls_row(g, b, i) : row) * NFP)[lane];
+    // one scalar base per array + 32-bit element offsets (every buffer is < 2^32 floats): keeps the kernel at 64 VGPRs
+    const float* __restrict__ C = g.C;
+    const float* __restrict__ V = g.V;
+    const unsigned l4 = 4u * lane;
+    const unsigned cb = (unsigned)b * (unsigned)g.c_cap;
+    const unsigned vb = CLS ? 0u : (unsigned)b * (unsigned)g.N;
+    const unsigned tool_row0 = 2u * g.N_o + (unsigned)b * g.M - g.N_o;        // + sender index (>= N_o) = class row
+    const unsigned self_row = g.self_row + (i >= g.N_o ? 1u : 0u);            // C row of this receiver's self-loop
+    const unsigned urow = CLS ? (i >= g.N_o ? tool_row0 + i : (unsigned)i) : (unsigned)row;
+    const f32x4 u = *reinterpret_cast<const f32x4*>(g.U + urow * (unsigned)NFP + l4);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int* snd = g.send + (long)b * g.edge_cap;
-    const float* Cb = g.C + (long)b * g.c_cap * NFP;
-    const float* Vb = CLS ? g.V : g.V + (long)b * g.N * NFP;
     int e = e0;
-    constexpr int UNR = CLS ? 2 : 4;                         // class-table rows are L2 hits: less to hide, fewer VGPRs
+    constexpr int UNR = 4;
     for (; e + UNR <= e1; e += UNR) {                        // 2*UNR independent 16-B loads in flight per lane
         f32x4 c[UNR], v[UNR];
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
             const int sj = snd[e + k];
-            const float* cr = (g.c_self && sj == i) ? g.c_self + (i >= g.N_o ? NFP : 0) : Cb + (long)(e + k) * NFP;
-            c[k] = reinterpret_cast<const f32x4*>(cr)[lane];
-            v[k] = reinterpret_cast<const f32x4*>(Vb + (CLS ? mp_cls_row(g, b, sj) : (long)sj) * NFP)[lane];
+            const unsigned crow = (g.dedupe && sj == i) ? self_row : cb + (unsigned)(e + k);
+            const unsigned vrow = CLS ? (sj >= g.N_o ? tool_row0 + sj : (unsigned)sj) : vb + (unsigned)sj;
+            c[k] = *reinterpret_cast<const f32x4*>(C + crow * (unsigned)NFP + l4);
+            v[k] = *reinterpret_cast<const f32x4*>(V + vrow * (unsigned)NFP + l4);
         }
 #pragma unroll
         for (int k = 0; k < UNR; ++k)
@@ -58,19 +66,20 @@ __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
     }
     for (; e < e1; ++e) {
         const int sj = snd[e];
-        const float* cr = (g.c_self && sj == i) ? g.c_self + (i >= g.N_o ? NFP : 0) : Cb + (long)e * NFP;
-        const f32x4 c = reinterpret_cast<const f32x4*>(cr)[lane];
-        const f32x4 v = reinterpret_cast<const f32x4*>(Vb + (CLS ? mp_cls_row(g, b, sj) : (long)sj) * NFP)[lane];
+        const unsigned crow = (g.dedupe && sj == i) ? self_row : cb + (unsigned)e;
+        const unsigned vrow = CLS ? (sj >= g.N_o ? tool_row0 + sj : (unsigned)sj) : vb + (unsigned)sj;
+        const f32x4 c = *reinterpret_cast<const f32x4*>(C + crow * (unsigned)NFP + l4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(V + vrow * (unsigned)NFP + l4);
 #pragma unroll
         for (int d = 0; d < 4; ++d) acc[d] += fmaxf((c[d] + u[d]) + v[d], 0.0f);
     }
-    reinterpret_cast<f32x4*>(g.agg + row * NFP)[lane] = acc;
+    *reinterpret_cast<f32x4*>(g.agg + (unsigned)row * (unsigned)NFP + l4) = acc;
 }
 
 hipError_t launch_mp(const GraphBufs& g, int first_round, hipStream_t st) {
     const int cls = g.cls_on && first_round;
     MpDev d{g.C, cls ? g.c_U : g.U, cls ? g.c_V : g.V, g.agg, g.send, g.row_ptr, g.B, g.N, g.edge_cap, g.c_cap,
-            cls, g.N_o, g.M, g.vmask, g.c_self};
+            cls, g.N_o, g.M, g.vmask, g.c_self ? 1 : 0, (unsigned)g.self_row};
     const long rows = (long)g.B * g.N;
     const dim3 grid((unsigned)((rows + MP_WAVES - 1) / MP_WAVES));
     if (cls) hipLaunchKernelGGL(k_mp<true>, grid, dim3(MP_WAVES * 64), 0, st, d);
