@@ -174,6 +174,16 @@ __device__ __forceinline__ bool pair_within(const EdgeLds& l, int N, float xi, f
 // rank counting over keys[0..nb): returns the k-th smallest key; optionally compacts the k smallest to the front.
 __device__ __forceinline__ unsigned long long select_kth(unsigned long long* keys, int nb, int k, bool compact) {
     const int lane = lane_id();
+    if (nb <= 64 && !compact) {                            // common case: one key per lane
+        const unsigned long long mine = lane < nb ? keys[lane] : KEY_INF;
+        int rank = 0;
+        for (int t = 0; t < nb; ++t) rank += keys[t] < mine ? 1 : 0;
+        const unsigned long long bal = __ballot(lane < nb && rank == k - 1);
+        const int src = __ffsll((long long)bal) - 1;
+        const unsigned lo = __shfl((unsigned)(mine & 0xffffffffull), src);
+        const unsigned hi = __shfl((unsigned)(mine >> 32), src);
+        return ((unsigned long long)hi << 32) | lo;
+    }
     unsigned long long mine[CAP / 64];
     int rank[CAP / 64];
 #pragma unroll

@@ -167,6 +167,17 @@ __device__ __forceinline__ void add_act(Act& a, const Act& b) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) a.t[t][r] += b.t[t][r];
 }
+template <int T0, int T1>
+__device__ __forceinline__ void add_rows_part(Act& a, const float* __restrict__ base, long row, int lane) {
+    const float* p = base + row * NFP + 4 * (lane >> 5);
+#pragma unroll
+    for (int t = T0; t < T1; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + 32 * t + 8 * q);
+            a.t[t][4 * q + 0] += v[0]; a.t[t][4 * q + 1] += v[1]; a.t[t][4 * q + 2] += v[2]; a.t[t][4 * q + 3] += v[3];
+        }
+}
 __device__ __forceinline__ void store_rows(const Act& a, float* __restrict__ base, long row, int lane, bool valid) {
     if (!valid) return;
     float* p = base + row * NFP + 4 * (lane >> 5);
@@ -184,12 +195,12 @@ __device__ __forceinline__ void store_rows(const Act& a, float* __restrict__ bas
 // Precondition: quarter 0 is in buffer 0 and a barrier has passed.  Every sweep runs with the NEXT quarter's
 // global->register loads in flight; the registers are written to the other buffer after the sweep.
 // Postcondition: the first NEXT floats of `next` (the following phase) are in buffer 0 and a barrier has passed.
-template <int NEXT>
+template <int NEXT, bool ZERO = true>
 __device__ __forceinline__ void layer160(float* lds, const float* __restrict__ w, const float* __restrict__ next,
                                          const Act& in, Act& out, int tid, int lane) {
     float* b0 = lds;
     float* b1 = lds + BUF_FLOATS;
-    zero(out);
+    if (ZERO) zero(out);                                     // else: accumulate on top of what `out` holds
     {
         Stager<Q_FLOATS> s;
         s.load(w + Q_FLOATS, tid);
@@ -373,20 +384,20 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     Stager<Q_FLOATS> sn;
     sn.load(g.w + WL::P_WB, tid);
     Act x, y;
-    load_rows(x, g.agg, rowc, lane);
-    sn.store(lds, tid);
-    __syncthreads();
-    layer160<Q_FLOATS>(lds, g.w + WL::P_WB, g.w + (LAST ? WL::P_P0 : WL::N_W2), x, y, tid, lane);
-    // x (the agg tile) is dead: reuse its 80 registers as the landing zone, one operand at a time.  Left to itself
-    // the compiler issues both 80-register row loads up front on top of the live accumulators and spills ~80 VGPRs;
-    // an opaque zero added to the row index, data-dependent on the accumulator, pins each load group in place.
+    // The residual terms seed the accumulator: y = P + eff, then y += Wb*agg.  All three row loads are issued here,
+    // together, instead of two of them stalling the chain after the Wb layer.
     const int pb = (int)(rowc / g.N), pi = (int)(rowc - (long)pb * g.N);
     const long crow = g.cls_on ? cls_row(g, pb, pi) : rowc;
-    load_rows(x, g.cls_on ? g.c_P : g.P, crow + pin_after(y), lane);
-    add_act(y, x);
     const bool ceff = g.cls_on && g.first_round;             // round 1: the previous effect is p_enc itself
-    load_rows(x, ceff ? g.c_eff : g.eff, (ceff ? crow : rowc) + pin_after(y), lane);
-    add_act(y, x);
+    sn.store(lds, tid);                                      // frees the staging registers before the row loads
+    __syncthreads();
+    load_rows(x, g.agg, rowc, lane);
+    load_rows(y, g.cls_on ? g.c_P : g.P, crow, lane);
+    // the third operand lands in temporaries: two batches keep it inside the register budget
+    add_rows_part<0, 2>(y, ceff ? g.c_eff : g.eff, ceff ? crow : rowc, lane);
+    materialize(y);
+    add_rows_part<2, 5>(y, ceff ? g.c_eff : g.eff, (ceff ? crow : rowc) + pin_after(y), lane);
+    layer160<Q_FLOATS, false>(lds, g.w + WL::P_WB, g.w + (LAST ? WL::P_P0 : WL::N_W2), x, y, tid, lane);
     relu_one(y, lane);                                       // y = new particle effect (slot 150 forced to 1)
     if (!LAST) {
         store_rows(y, g.eff, row, lane, valid);
