@@ -273,6 +273,7 @@ def _rollout_candidate(W, pstep, obj0, obj_mask, eef_xz, eef_delta, repeat, task
 
 def dynamics(W, pstep, state, action, task, physics_param=0.5, trace=None):
     """forward_dynamics.py:12-205.  state (N_o,3); action (B,H,4).  Returns dict like the reference.
+    physics_param: scalar, or (N_o,) per-particle values (the (B,n_p) branch of model.py:200-204).
 
     Candidates are independent (SURVEY §8(e)), so each is stepped alone for exactly repeat[b,li] steps;
     the reference steps everyone to the batch max and discards the surplus (:156-161) - same outputs.
@@ -293,7 +294,7 @@ def dynamics(W, pstep, state, action, task, physics_param=0.5, trace=None):
             if li > 0:
                 obj = out[b, li - 1]                                        # :37-38
             cap = _rollout_candidate(W, pstep, obj, ones, xz[b, li], delta[b, li], rep[b, li], task, "min",
-                                     F32(physics_param), task["max_nR"], tr)
+                                     np.asarray(physics_param, F32), task["max_nR"], tr)
             if cap is not None:
                 out[b, li] = cap                                            # repeat==0 leaves zeros (:32,:160)
         if trace is not None:
@@ -314,7 +315,7 @@ def dynamics_masked(W, pstep, state_init, state_mask, action, task, physics_para
     for b in range(B):
         tr = [] if trace is not None else None
         cap = _rollout_candidate(W, pstep, state_init[b], state_mask[b], xz[b], delta[b], rep[b], task, "mean",
-                                 F32(physics_param), task["max_nR"], tr)
+                                 np.asarray(physics_param, F32), task["max_nR"], tr)
         if cap is not None:
             out[b] = cap
         if trace is not None:

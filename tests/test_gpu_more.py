@@ -1,0 +1,242 @@
+"""More GPU parity (-m gpu): path cross-checks, full-size configs, edge cases and error behaviour."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import _cfg, _ppm, _edges_to_lists, POS_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ag():
+    import adaptigraph_amd
+    return adaptigraph_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import adaptigraph_oracle
+    return adaptigraph_oracle
+
+
+def _task(material, **kw):
+    base = dict(sim_real_ratio=10, max_n=1, n_his=4, material=material, material_dims={material: 1},
+                material_indices={material: 0})
+    cfgs = {
+        "rope": dict(adj_thresh=0.5, topk=10, connect_tools_all=False, push_length=0.1, gripper_enable=False,
+                     eef_num=1, pusher_points=[[0.0, 0.0, 0.12]], max_nR=6000),
+        "granular": dict(adj_thresh=0.4, topk=20, connect_tools_all=False, push_length=0.2, gripper_enable=False,
+                         eef_num=5, max_nR=30000,
+                         pusher_points=[[0, 0, 0.1], [0, 0.05, 0.1], [0, 0.025, 0.1], [0, -0.025, 0.1], [0, -0.05, 0.1]]),
+        "cloth": dict(adj_thresh=0.75, topk=5, connect_tools_all=True, push_length=0.1, gripper_enable=True,
+                      eef_num=1, pusher_points=[[0.0, 0.0, 0.17]], max_nR=16000),
+    }
+    base.update(cfgs[material])
+    base.update(kw)
+    return base
+
+
+def _grid(side, pitch, jitter, rng):
+    g = (np.arange(side) - (side - 1) / 2.0) * pitch
+    xx, zz = np.meshgrid(g, g, indexing="ij")
+    p = np.stack([xx.ravel() - 2.0, np.zeros(side * side), zz.ravel() + 1.0], 1)
+    return (p + rng.normal(0, jitter, p.shape)).astype(np.float32)
+
+
+def _rope(n, rng):
+    t = np.linspace(0, 1, n)
+    p = np.stack([-2 + 3 * t, 0 * t, 0.5 * np.sin(6 * t)], 1)
+    return (p + rng.normal(0, 0.01, p.shape)).astype(np.float32)
+
+
+def _actions(cloud, B, H, rep, rng, spread=0.6):
+    a = np.zeros((B, H, 4), np.float32)
+    c = cloud.mean(0)
+    a[..., 0] = c[0] + rng.uniform(-spread, spread, (B, H))
+    a[..., 1] = c[2] + rng.uniform(-spread, spread, (B, H))
+    a[..., 2] = rng.uniform(-3.1, 3.1, (B, H))
+    rep = np.asarray(rep, np.float32)
+    a[..., 3] = (rep[:, None] if rep.ndim == 1 else rep) + 0.5
+    return a
+
+
+def _model(ag, O, material, seed, dev, pstep=3):
+    W = O.random_weights(seed)
+    m = ag.DynamicsPredictor(*_cfg(material, pstep), dev)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    return W, m
+
+
+def test_rollout_step_equals_plain_forward_bitwise(ag, O, dev):
+    """The rollout engine (class table, self-loop constants, on-device bookkeeping) and the plain ag_forward path
+    (every row encoded, every edge encoded) must give the same bits for one step on the same graph."""
+    rng = np.random.default_rng(3)
+    task = _task("cloth")
+    W, m = _model(ag, O, "cloth", 3, dev)
+    cloud = _grid(14, 0.3, 0.02, rng)
+    N_o, M = cloud.shape[0], 1
+    B = 3
+    a = _actions(cloud, B, 1, 1, rng)
+    out = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(a).to(dev), m, dev, _ppm(task, "cloth"))
+    # the same step assembled by hand, reference-style
+    dec, _ = O.decode_action(a, task["push_length"])
+    xz, delta = O.tool_keypoints(dec, a[..., 2], task)
+    state = np.zeros((B, 4, N_o + M, 3), np.float32)
+    action = np.zeros((B, N_o + M, 3), np.float32)
+    for b in range(B):
+        y = np.float32(np.float32(cloud[:, 1].min()) + np.float32(0.01 * task["sim_real_ratio"]))
+        tool = np.array([[xz[b, 0, 0, 0], y, xz[b, 0, 0, 1]]], np.float32)
+        state[b, :] = np.concatenate([cloud, tool], 0)[None]
+        action[b, N_o:] = delta[b, 0]
+    attrs = np.zeros((B, N_o + M, 2), np.float32)
+    attrs[:, :N_o, 0] = 1
+    attrs[:, N_o:, 1] = 1
+    mask = torch.ones((B, N_o + M), dtype=torch.bool, device=dev)
+    toolm = torch.zeros((B, N_o + M), dtype=torch.bool, device=dev)
+    toolm[:, N_o:] = True
+    st = torch.from_numpy(state).to(dev)
+    el = ag.construct_edges_index(st[:, -1], task["adj_thresh"], mask, toolm, task["topk"], True)
+    pos, _ = m(state=st, attrs=torch.from_numpy(attrs).to(dev), edges=el,
+               p_instance=torch.ones((B, N_o, 1), device=dev), action=torch.from_numpy(action).to(dev),
+               cloth_physics_param=torch.full((B, 1), 0.5, device=dev))
+    assert torch.equal(out["state_seqs"][:, 0], pos)
+
+
+@pytest.mark.parametrize("material,cloud_fn,B,H,rep", [
+    ("rope", lambda r: _rope(300, r), 64, 2, 3),                       # BASELINE configs[1] shape
+    ("granular", lambda r: _grid(32, 0.12, 0.02, r), 6, 1, 3),         # configs[2] particle count, 5-point pusher
+    ("cloth", lambda r: _grid(45, 0.3, 0.02, r), 5, 1, 2),             # configs[3] particle count
+])
+def test_full_size_configs_vs_oracle_and_sharding(ag, O, dev, material, cloud_fn, B, H, rep):
+    rng = np.random.default_rng(17)
+    task = _task(material)
+    W, m = _model(ag, O, material, 17, dev)
+    cloud = cloud_fn(rng)
+    a = _actions(cloud, B, H, rep, rng)
+    full = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(a).to(dev), m, dev, _ppm(task, material))
+    seq = full["state_seqs"]
+    assert torch.isfinite(seq).all()
+    # oracle on the first two candidates (the dense reference cannot run these sizes whole; the oracle can)
+    want = O.dynamics(W, 3, cloud, a[:2], task)
+    err = np.abs(seq[:2].cpu().numpy() - want["state_seqs"]).max()
+    assert err <= POS_TOL, err
+    # size-independent property: any sub-batch / chunking gives the same bits per candidate
+    part = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(a[1:4]).to(dev), m, dev, _ppm(task, material))
+    assert torch.equal(part["state_seqs"], seq[1:4])
+    m.engine(dev).set_chunk(2)
+    again = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(a).to(dev), m, dev, _ppm(task, material))
+    m.engine(dev).set_chunk(0)
+    assert torch.equal(again["state_seqs"], seq)
+
+
+def test_repeat_zero_and_mixed_repeats(ag, O, dev):
+    """action_repeat == 0 leaves zeros in state_seqs and the next look-ahead step starts from them (forward_dynamics.py:32,38)."""
+    rng = np.random.default_rng(5)
+    task = _task("rope")
+    W, m = _model(ag, O, "rope", 5, dev)
+    cloud = _rope(80, rng)
+    a = _actions(cloud, 3, 2, [[0, 2], [3, 0], [1, 4]], rng)
+    out = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(a).to(dev), m, dev, _ppm(task, "rope"))
+    want = O.dynamics(W, 3, cloud, a, task)
+    got = out["state_seqs"].cpu().numpy()
+    assert np.all(got[0, 0] == 0) and np.all(got[1, 1] == 0)
+    assert np.abs(got - want["state_seqs"]).max() <= POS_TOL
+
+
+def test_per_particle_physics_and_pstep1(ag, O, dev):
+    rng = np.random.default_rng(6)
+    task = _task("rope")
+    cloud = _rope(90, rng)
+    a = _actions(cloud, 2, 1, 3, rng)
+    phys = rng.uniform(0.1, 0.9, 90).astype(np.float32)
+    for pstep in (1, 3):
+        W, m = _model(ag, O, "rope", 6 + pstep, dev, pstep)
+        ppm = _ppm(task, "rope")
+        ppm.physics_param = {"rope": torch.from_numpy(phys)}
+        out = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(a).to(dev), m, dev, ppm)
+        want = O.dynamics(W, pstep, cloud, a, task, physics_param=phys)
+        assert np.abs(out["state_seqs"].cpu().numpy() - want["state_seqs"]).max() <= POS_TOL
+
+
+def test_masked_rollout_with_holes_vs_oracle(ag, O, dev):
+    """dynamics_masked with a NON-prefix mask: p_instance marks the first `count` rows (forward_dynamics.py:294-300),
+    attrs follow the mask (:287) - both quirks are reproduced."""
+    rng = np.random.default_rng(8)
+    task = _task("rope", max_nR=4000)
+    W, m = _model(ag, O, "rope", 8, dev)
+    B, n = 3, 100
+    state = np.zeros((B, n, 3), np.float32)
+    mask = np.zeros((B, n), bool)
+    for b in range(B):
+        state[b] = _rope(n, rng)
+        mask[b] = rng.uniform(size=n) > (0.0, 0.2, 0.35)[b]
+        state[b, ~mask[b]] = 0
+    a = _actions(state[0], B, 1, [3, 2, 4], rng)[:, 0]
+    out = ag.dynamics_masked(torch.from_numpy(state).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(a).to(dev),
+                             m, dev, _ppm(task, "rope"))
+    want = O.dynamics_masked(W, 3, state, mask, a, task)
+    assert np.abs(out["state_seqs"].cpu().numpy() - want["state_seqs"]).max() <= POS_TOL
+
+
+def test_unsupported_and_invalid_inputs_raise(ag, O, dev):
+    big = torch.zeros((1, 5000, 3), device=dev)
+    ones = torch.ones((1, 5000), dtype=torch.bool, device=dev)
+    with pytest.raises(NotImplementedError):
+        ag.construct_edges_index(big, 0.5, ones, ~ones, 10, False, edge_cap=10)
+    small = torch.rand((1, 400, 3), device=dev)
+    ones = torch.ones((1, 400), dtype=torch.bool, device=dev)
+    with pytest.raises(NotImplementedError):
+        ag.construct_edges_index(small, 0.5, ones, ~ones, 200, False, edge_cap=10)
+    mc, mat, ds = _cfg("rope")
+    mc = dict(mc, nf_effect=128, nf_particle=128, nf_relation=128)
+    with pytest.raises(NotImplementedError):
+        ag.DynamicsPredictor(mc, mat, ds, dev)
+    mc2, mat2, ds2 = _cfg("rope")
+    with pytest.raises(NotImplementedError):
+        ag.DynamicsPredictor(dict(mc2, offset_dim=3), mat2, ds2, dev)
+    _, m = _model(ag, O, "rope", 1, dev)
+    with pytest.raises(AssertionError):          # two physics keys (model.py:186-187)
+        m(state=torch.zeros((1, 4, 3, 3), device=dev), attrs=torch.zeros((1, 3, 2), device=dev),
+          Rr=torch.zeros((1, 1, 3), device=dev), Rs=torch.zeros((1, 1, 3), device=dev),
+          p_instance=torch.ones((1, 2, 1), device=dev), action=torch.zeros((1, 3, 3), device=dev),
+          a_physics_param=torch.zeros((1, 1)), b_physics_param=torch.zeros((1, 1)))
+    task = _task("rope", pusher_points=[[0, 0, 0.1]] * 3, eef_num=3)
+    with pytest.raises(NotImplementedError, match="pusher"):
+        ag.dynamics(torch.zeros((10, 3), device=dev), torch.zeros((1, 1, 4), device=dev), m, dev, _ppm(task, "rope"))
+    with pytest.raises(TypeError):
+        ag.dynamics(torch.zeros((10, 3), device=dev), torch.zeros((1, 1, 4), device=dev), torch.nn.Linear(1, 1), dev,
+                    _ppm(_task("rope"), "rope"))
+
+
+def test_edge_overflow_reports_true_count(ag, dev):
+    """ag_build_edges with a too-small edge_cap: nothing written, n_edges still the true count (pad_torch semantics)."""
+    rng = np.random.default_rng(2)
+    pos = torch.from_numpy(_grid(12, 0.1, 0.01, rng)[None]).to(dev)
+    ones = torch.ones((1, 144), dtype=torch.bool, device=dev)
+    big = ag.construct_edges_index(pos, 0.5, ones, ~ones, 10, False)
+    small = ag.construct_edges_index(pos, 0.5, ones, ~ones, 10, False, edge_cap=100)
+    assert int(small.n_edges[0]) == int(big.n_edges[0]) > 100
+    assert torch.equal(small.row_ptr, big.row_ptr)
+
+
+def test_empty_and_degenerate_graphs(ag, O, dev):
+    """No valid particle at all / a single particle / everything out of radius."""
+    pos = torch.rand((2, 6, 3), device=dev) * 100
+    none = torch.zeros((2, 6), dtype=torch.bool, device=dev)
+    el = ag.construct_edges_index(pos, 0.5, none, none, 3, False)
+    assert el.n_edges.tolist() == [0, 0] and int(el.row_ptr.abs().sum()) == 0
+    allv = ~none
+    el = ag.construct_edges_index(pos, 1e-3, allv, none, 3, True)       # only self-loops survive
+    for (r, s) in _edges_to_lists(el):
+        assert np.array_equal(r, np.arange(6)) and np.array_equal(s, np.arange(6))
+    Rr, Rs = el.to_dense()
+    assert Rr.shape == (2, 6, 6)
