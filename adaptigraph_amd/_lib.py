@@ -19,12 +19,13 @@ AG_ERR_UNSUPPORTED = -4
 AG_ERR_NO_WEIGHTS = -5
 
 KERNEL_FAMILIES = ["edge_count", "edge_emit", "prep", "node_enc", "edge_enc", "mp", "node_prop", "node_final",
-                   "roll_init", "roll_update"]
+                   "roll_init", "roll_update", "cost"]
 
 # exactly the symbols include/adaptigraph_amd.h declares (tests/test_abi.py checks both directions)
 EXPORTS = ["ag_abi_version", "ag_ctx_create", "ag_ctx_destroy", "ag_last_error", "ag_ctx_load_weights",
            "ag_ctx_set_chunk", "ag_build_edges", "ag_forward", "ag_rollout", "ag_rollout_async",
-           "ag_ctx_set_profiling", "ag_ctx_kernel_stats", "ag_ctx_reset_stats"]
+           "ag_ctx_set_profiling", "ag_ctx_kernel_stats", "ag_ctx_reset_stats",
+           "ag_cost_chamfer", "ag_cost_state_stats", "ag_cost_penalty"]
 
 
 class AgDims(C.Structure):
@@ -65,6 +66,9 @@ def load():
     lib.ag_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.ag_rollout.argtypes = [vp, vp, C.POINTER(AgRolloutParams), vp, vp, vp, vp, vp, vp, vp]  # ..., h_repeat, d_phys_vec, d_state_seqs
     lib.ag_rollout_async.argtypes = [vp, vp, C.POINTER(AgRolloutParams), vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ag_cost_chamfer.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.ag_cost_state_stats.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.ag_cost_penalty.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]
     lib.ag_ctx_set_profiling.argtypes = [vp, i32]
     lib.ag_ctx_kernel_stats.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.ag_ctx_reset_stats.argtypes = [vp]

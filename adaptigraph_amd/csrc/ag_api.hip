@@ -21,7 +21,7 @@ using namespace ag;
 namespace {
 
 const char* kFamilyNames[FAM_COUNT] = {"edge_count", "edge_emit", "prep", "node_enc", "edge_enc",
-                                       "mp", "node_prop", "node_final", "roll_init", "roll_update"};
+                                       "mp", "node_prop", "node_final", "roll_init", "roll_update", "cost"};
 
 struct Slab {
     char* base = nullptr;
@@ -562,6 +562,44 @@ int ag_rollout(ag_ctx* c, void* stream, const ag_rollout_params* p, const float*
     HIPCHK(c, hipMemcpyAsync(&seen, c->d_overflow, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     if (seen > p->max_nR) return fail(c, AG_ERR_MAX_NR, "Exceeds max dims: a graph had %d edges, max_nR=%d", seen, p->max_nR);
+    return AG_OK;
+}
+
+int ag_cost_chamfer(ag_ctx* c, void* stream, const float* d_x, const float* d_y, const uint8_t* d_xmask,
+                    const uint8_t* d_ymask, int32_t R, int32_t N, int32_t M, int32_t By, float* d_out) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_x || !d_y || !d_out || R < 1 || N < 1 || M < 1 || (By != 1 && By != R))
+        return fail(c, AG_ERR_INVALID, "ag_cost_chamfer: bad arguments R=%d N=%d M=%d By=%d", R, N, M, By);
+    if ((size_t)N + (size_t)M > chamfer_max_points())
+        return fail(c, AG_ERR_UNSUPPORTED, "ag_cost_chamfer: N+M=%d exceeds the LDS tile (%zu points)", N + M, chamfer_max_points());
+    HIPCHK(c, hipSetDevice(c->device));
+    c->prof_stream = static_cast<hipStream_t>(stream);
+    Scoped p(c, FAM_COST);
+    HIPCHK(c, launch_chamfer(d_x, d_y, d_xmask, d_ymask, R, N, M, By, d_out, static_cast<hipStream_t>(stream)));
+    return AG_OK;
+}
+
+int ag_cost_state_stats(ag_ctx* c, void* stream, const float* d_state, int32_t R, int32_t N, const float* h_box4,
+                        float* d_out) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_state || !d_out || R < 1 || N < 1) return fail(c, AG_ERR_INVALID, "ag_cost_state_stats: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->prof_stream = static_cast<hipStream_t>(stream);
+    Scoped p(c, FAM_COST);
+    HIPCHK(c, launch_state_stats(d_state, R, N, h_box4, d_out, static_cast<hipStream_t>(stream)));
+    return AG_OK;
+}
+
+int ag_cost_penalty(ag_ctx* c, void* stream, const float* d_state_pred, const float* d_action,
+                    const float* d_state_init, int32_t B, int32_t H, int32_t N, int32_t kind, float ratio, float* d_out) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_state_pred || !d_action || !d_state_init || !d_out || B < 1 || H < 1 || N < 1)
+        return fail(c, AG_ERR_INVALID, "ag_cost_penalty: bad arguments");
+    if (kind < 0 || kind > 2) return fail(c, AG_ERR_UNSUPPORTED, "penalty kind %d not implemented", kind);
+    HIPCHK(c, hipSetDevice(c->device));
+    c->prof_stream = static_cast<hipStream_t>(stream);
+    Scoped p(c, FAM_COST);
+    HIPCHK(c, launch_penalty(d_state_pred, d_action, d_state_init, B, H, N, kind, ratio, d_out, static_cast<hipStream_t>(stream)));
     return AG_OK;
 }
 

@@ -57,7 +57,7 @@ struct WeightLayout {
 
 // ---- kernel families (profiling ids) ------------------------------------------------------------------
 enum Family { FAM_EDGE_COUNT = 0, FAM_EDGE_EMIT, FAM_PREP, FAM_NODE_ENC, FAM_EDGE_ENC, FAM_MP, FAM_NODE_PROP,
-              FAM_NODE_FINAL, FAM_ROLL_INIT, FAM_ROLL_UPDATE, FAM_COUNT };
+              FAM_NODE_FINAL, FAM_ROLL_INIT, FAM_ROLL_UPDATE, FAM_COST, FAM_COUNT };
 
 // ---- launchers (defined in the .hip files) ------------------------------------------------------------
 struct EdgeArgs {
@@ -145,6 +145,14 @@ struct RollArgs {
     const int* repeat;                        // device (Bfull,H)
     float* state_seqs;                        // (Bfull,H,N_o,3)
 };
+// cost kernels (ag_cost.hip)
+hipError_t launch_chamfer(const float* x, const float* y, const uint8_t* xm, const uint8_t* ym, int R, int N, int M,
+                          int By, float* out, hipStream_t st);
+hipError_t launch_state_stats(const float* state, int R, int N, const float* box4, float* out, hipStream_t st);
+hipError_t launch_penalty(const float* state_pred, const float* action, const float* state_init, int B, int H, int N,
+                          int kind, float ratio, float* out, hipStream_t st);
+size_t chamfer_max_points();
+
 hipError_t launch_roll_init(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);
 hipError_t launch_roll_update(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);
 

@@ -1,0 +1,204 @@
+// Per-candidate cost kernels: replace reference src/planning/losses.py:4-92 and the particle
+// reductions of running_cost (src/planning/plan.py:41-44).  gfx950 only.
+//
+// All of them are "one workgroup per (candidate, look-ahead step) row, sweep the particles, tree-reduce": HBM/LDS-bound
+// pairwise or pointwise passes.  chamfer is the heavy one (N*M distance evaluations per row in both directions): both
+// clouds sit in LDS as SoA, every lane owns one point and scans the other cloud through LDS broadcasts - the same
+// tiling idea as the edge builder.  No atomics: fixed reduction trees, bit-reproducible.
+#include "ag_common.h"
+
+namespace ag {
+
+constexpr int CT = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int o = CT / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_min(float v, float* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int o = CT / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fminf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int o = CT / 2; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// ---- chamfer(x, y) = mean_j min_i |x_i - y_j| + mean_i min_j |x_i - y_j|        losses.py:4-10
+// x (R,N,3); y (By,M,3) with By == 1 (one target for every row, plan.py:146) or By == R; optional validity masks
+// (mean_chamfer, losses.py:12-24, keeps only masked-in points of both clouds).
+struct ChamferDev {
+    const float* x; const float* y; const uint8_t* xm; const uint8_t* ym; float* out;
+    int R, N, M, By;
+};
+__global__ __launch_bounds__(CT) void k_chamfer(ChamferDev a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float red[CT];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    float* xs = sm;                 // [3][N]
+    float* ys = sm + 3 * a.N;       // [3][M]
+    const float* xr = a.x + (long)r * a.N * 3;
+    const float* yr = a.y + (long)(a.By == 1 ? 0 : r) * a.M * 3;
+    const uint8_t* xm = a.xm ? a.xm + (long)r * a.N : nullptr;
+    const uint8_t* ym = a.ym ? a.ym + (long)(a.By == 1 ? 0 : r) * a.M : nullptr;
+    const float BIG = 3.0e38f;
+    for (int i = tid; i < a.N; i += CT) {
+        const bool v = xm ? xm[i] != 0 : true;             // masked-out points are parked at "infinity"
+        xs[i] = v ? xr[3 * i] : BIG; xs[a.N + i] = v ? xr[3 * i + 1] : BIG; xs[2 * a.N + i] = v ? xr[3 * i + 2] : BIG;
+    }
+    for (int j = tid; j < a.M; j += CT) {
+        const bool v = ym ? ym[j] != 0 : true;
+        ys[j] = v ? yr[3 * j] : BIG; ys[a.M + j] = v ? yr[3 * j + 1] : BIG; ys[2 * a.M + j] = v ? yr[3 * j + 2] : BIG;
+    }
+    __syncthreads();
+    float sum_y = 0.f, cnt_y = 0.f, sum_x = 0.f, cnt_x = 0.f;
+    for (int j = tid; j < a.M; j += CT) {                  // for every y point the nearest x
+        const float yx = ys[j], yy = ys[a.M + j], yz = ys[2 * a.M + j];
+        if (yx >= BIG) continue;
+        float m = BIG;
+        for (int i = 0; i < a.N; ++i) {
+            const float dx = xs[i] - yx, dy = xs[a.N + i] - yy, dz = xs[2 * a.N + i] - yz;
+            const float d = xs[i] >= BIG ? BIG : (dx * dx + dy * dy) + dz * dz;
+            m = fminf(m, d);
+        }
+        sum_y += sqrtf(m); cnt_y += 1.f;
+    }
+    for (int i = tid; i < a.N; i += CT) {                  // for every x point the nearest y
+        const float xx = xs[i], xy = xs[a.N + i], xz = xs[2 * a.N + i];
+        if (xx >= BIG) continue;
+        float m = BIG;
+        for (int j = 0; j < a.M; ++j) {
+            const float dx = xx - ys[j], dy = xy - ys[a.M + j], dz = xz - ys[2 * a.M + j];
+            const float d = ys[j] >= BIG ? BIG : (dx * dx + dy * dy) + dz * dz;
+            m = fminf(m, d);
+        }
+        sum_x += sqrtf(m); cnt_x += 1.f;
+    }
+    const float sy = block_sum(sum_y, red), cy = block_sum(cnt_y, red);
+    const float sx = block_sum(sum_x, red), cx = block_sum(cnt_x, red);
+    if (tid == 0) a.out[r] = sy / cy + sx / cx;
+}
+
+// ---- per-row particle statistics of a (R,N,3) state tensor: box_loss (losses.py:26-35) and the x/z bounds that
+// running_cost turns into the bounding-box penalty (plan.py:41-51).  out (R,5) = [box_loss, xmin, xmax, zmin, zmax]
+struct StatsDev { const float* state; float* out; int R, N; int has_box; float bx0, bx1, bz0, bz1; };
+__global__ __launch_bounds__(CT) void k_state_stats(StatsDev a) {
+    __shared__ float red[CT];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* s = a.state + (long)r * a.N * 3;
+    float acc = 0.f, xmin = 3.0e38f, xmax = -3.0e38f, zmin = 3.0e38f, zmax = -3.0e38f;
+    for (int i = tid; i < a.N; i += CT) {
+        const float x = s[3 * i], z = s[3 * i + 2];
+        xmin = fminf(xmin, x); xmax = fmaxf(xmax, x); zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+        if (a.has_box) {
+            const float xd = fmaxf(a.bx0 - x, 0.f) + fmaxf(x - a.bx1, 0.f);
+            const float zd = fmaxf(a.bz0 - z, 0.f) + fmaxf(z - a.bz1, 0.f);
+            acc += sqrtf(xd * xd + zd * zd);
+        }
+    }
+    const float t = block_sum(acc, red);
+    const float a0 = block_min(xmin, red), a1 = block_max(xmax, red), a2 = block_min(zmin, red), a3 = block_max(zmax, red);
+    if (tid == 0) {
+        float* o = a.out + (long)r * 5;
+        o[0] = t / (float)a.N; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3;
+    }
+}
+
+// ---- collision penalties (losses.py:37-92).  One workgroup per (b,h).  kind 0 rope, 1 cloth, 2 granular.
+// out (B,H,2): [exp(-max(dmin - size, 0)*100), min(dmax, 0.4*ratio)] - the second entry is only meaningful for cloth,
+// whose final value needs the batch-global maximum of it (losses.py:62).
+struct PenDev {
+    const float* state_pred; const float* action; const float* state_init; float* out;
+    int B, H, N, kind; float ratio;
+};
+__global__ __launch_bounds__(CT) void k_penalty(PenDev a) {
+    __shared__ float red[CT];
+    const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H, tid = threadIdx.x;
+    const float* act = a.action + (long)bh * 4;
+    // cloth always looks at the initial cloud (losses.py:55); rope / granular at the cloud BEFORE step h (:42-43, :83-84)
+    const float* s = (a.kind == 1 || h == 0) ? a.state_init : a.state_pred + ((long)b * a.H + (h - 1)) * a.N * 3;
+    const float x0 = act[0], z0 = act[1];
+    float px[9], pz[9];
+    int npt = 1;
+    px[0] = x0; pz[0] = z0;
+    if (a.kind == 2) {                                       // 9 points along the pusher blade (losses.py:70-82)
+        const float rad = 0.05f * a.ratio;
+        const float dx = rad * sinf(act[2]), dz = -rad * cosf(act[2]);
+        const float c[9] = {-1.f, -0.75f, -0.5f, -0.25f, 0.f, 0.25f, 0.5f, 0.75f, 1.f};
+        npt = 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            px[k] = c[k] < 0.f ? x0 - (-c[k]) * dx : x0 + c[k] * dx;
+            pz[k] = c[k] < 0.f ? z0 - (-c[k]) * dz : z0 + c[k] * dz;
+        }
+    }
+    float dmin = 3.0e38f, dmax = 0.f;
+    for (int i = tid; i < a.N; i += CT) {
+        const float sx = s[3 * i], sz = s[3 * i + 2];
+        for (int k = 0; k < npt; ++k) {
+            const float ex = px[k] - sx, ez = pz[k] - sz;
+            const float d = sqrtf(ex * ex + ez * ez);
+            dmin = fminf(dmin, d); dmax = fmaxf(dmax, d);
+        }
+    }
+    const float mn = block_min(dmin, red), mx = block_max(dmax, red);
+    if (tid == 0) {
+        const float size = (a.kind == 1 ? 0.005f : 0.02f) * a.ratio;
+        a.out[(long)bh * 2 + 0] = expf(-fmaxf(mn - size, 0.f) * 100.f);
+        a.out[(long)bh * 2 + 1] = fminf(mx, 0.4f * a.ratio);
+    }
+}
+
+hipError_t launch_chamfer(const float* x, const float* y, const uint8_t* xm, const uint8_t* ym, int R, int N, int M,
+                          int By, float* out, hipStream_t st) {
+    ChamferDev a{x, y, xm, ym, out, R, N, M, By};
+    const size_t lds = (size_t)(3 * N + 3 * M) * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chamfer),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_chamfer, dim3(R), dim3(CT), lds, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_state_stats(const float* state, int R, int N, const float* box4, float* out, hipStream_t st) {
+    StatsDev a{state, out, R, N, box4 ? 1 : 0, box4 ? box4[0] : 0.f, box4 ? box4[1] : 0.f, box4 ? box4[2] : 0.f,
+               box4 ? box4[3] : 0.f};
+    hipLaunchKernelGGL(k_state_stats, dim3(R), dim3(CT), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_penalty(const float* state_pred, const float* action, const float* state_init, int B, int H, int N,
+                          int kind, float ratio, float* out, hipStream_t st) {
+    PenDev a{state_pred, action, state_init, out, B, H, N, kind, ratio};
+    hipLaunchKernelGGL(k_penalty, dim3(B * H), dim3(CT), 0, st, a);
+    return hipGetLastError();
+}
+size_t chamfer_max_points() { return (160 * 1024 - 2048) / 12; }
+
+}  // namespace ag

@@ -40,7 +40,7 @@ extern "C" {
 #define AG_ERR_UNSUPPORTED -4  /* configuration outside what the kernels implement                            */
 #define AG_ERR_NO_WEIGHTS -5   /* forward/rollout before ag_ctx_load_weights                                   */
 
-#define AG_ABI_VERSION 1
+#define AG_ABI_VERSION 2
 #define AG_NUM_WEIGHT_TENSORS 22
 
 typedef struct ag_ctx ag_ctx;
@@ -137,6 +137,26 @@ int ag_rollout_async(ag_ctx* ctx, void* stream, const ag_rollout_params* p, cons
                      const uint8_t* d_obj_mask, const float* d_eef_xz, const float* d_eef_delta,
                      const int32_t* h_repeat, const float* d_phys_vec, float* d_state_seqs,
                      int32_t* d_overflow_flag);
+
+/* ---- Per-candidate cost functions: SURVEY §8(f) rank 1 (reference src/planning/losses.py, src/planning/plan.py:27-59) ---- */
+
+/* chamfer(x, y) (losses.py:4-10): d_x (R,N,3); d_y (By,M,3) with By == 1 (one target for all rows, plan.py:146) or
+ * By == R; optional uint8 masks d_xmask (R,N), d_ymask (By,M) keep only masked-in points (mean_chamfer, losses.py:12-24).
+ * d_out (R,).  N + M must fit the LDS tile (<= ~13k points). */
+int ag_cost_chamfer(ag_ctx* ctx, void* stream, const float* d_x, const float* d_y, const uint8_t* d_xmask,
+                    const uint8_t* d_ymask, int32_t R, int32_t N, int32_t M, int32_t By, float* d_out);
+
+/* Particle statistics of d_state (R,N,3) -> d_out (R,5) = [box_loss, xmin, xmax, zmin, zmax]: box_loss (losses.py:26-35)
+ * against h_box4 = {xmin, xmax, zmin, zmax} (NULL: entry 0 is 0), and the x/z bounds running_cost needs (plan.py:41-44). */
+int ag_cost_state_stats(ag_ctx* ctx, void* stream, const float* d_state, int32_t R, int32_t N, const float* h_box4,
+                        float* d_out);
+
+/* Collision penalties (losses.py:37-92): kind 0 rope, 1 cloth, 2 granular.  d_state_pred (B,H,N,3), d_action (B,H,4)
+ * raw [x,z,theta,len], d_state_init (N,3).  d_out (B,H,2) = [exp(-max(dmin - size,0)*100), min(dmax, 0.4*ratio)];
+ * rope/granular: entry 0 is the penalty; cloth: 1 - e0 - 0.2 * e1 / max_batch(e1) (the caller owns the global max). */
+int ag_cost_penalty(ag_ctx* ctx, void* stream, const float* d_state_pred, const float* d_action,
+                    const float* d_state_init, int32_t B, int32_t H, int32_t N, int32_t kind, float sim_real_ratio,
+                    float* d_out);
 
 /* Introspection for bench.py / tests: HIP-event time of every launch of a kernel family, recorded on the stream the
  * kernels run on.  family_mask bit i enables family i of: edge_count, edge_emit, prep, node_enc, edge_enc, mp,

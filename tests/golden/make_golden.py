@@ -427,5 +427,70 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--costs" not in sys.argv:
     main()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Row (f) rank 1 of SURVEY §8: per-candidate cost functions (src/planning/losses.py:4-92) and running_cost
+# (src/planning/plan.py:27-59).  planning.losses imports with torch/numpy alone.  plan.py's module-level imports pull
+# in robot/vision packages that are absent here, so running_cost is taken from plan.py by parsing the file and
+# compiling that one function (nothing of it is copied into the repo; only its outputs are stored).
+def import_costs():
+    import ast
+    sys.path.insert(0, REF)
+    from planning import losses
+    src = open(f"{REF}/planning/plan.py").read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "running_cost"][0]
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), f"{REF}/planning/plan.py", "exec"), ns)
+    return losses, ns["running_cost"]
+
+
+def gen_cost_cases(name):
+    from functools import partial
+    losses, running_cost = import_costs()
+    rng = np.random.default_rng(23)
+    store = {}
+    B, H, N, M = 6, 3, 150, 211
+    cloud = grid_cloud(13, 0.3, 0.02, rng)[:N]
+    state = (cloud[None, None] + rng.normal(0, 0.15, (B, H, N, 3))).astype(np.float32)
+    target = (cloud[rng.integers(0, N, M)] + np.float32([0.6, 0.0, 0.4]) + rng.normal(0, 0.05, (M, 3))).astype(np.float32)
+    action = np.zeros((B, H, 4), np.float32)
+    action[..., 0] = cloud[:, 0].mean() + rng.uniform(-2.5, 2.5, (B, H))
+    action[..., 1] = cloud[:, 2].mean() + rng.uniform(-2.5, 2.5, (B, H))
+    action[0, 0, :2] = cloud[40, [0, 2]] + 0.01          # a start point on the object (collision penalty ~1)
+    action[..., 2] = rng.uniform(-3.14, 3.14, (B, H))
+    action[..., 3] = rng.uniform(2, 10, (B, H))
+    ts, ta, tc, tt = (torch.from_numpy(a) for a in (state, action, cloud, target))
+    store.update(state=state, action=action, state_cur=cloud, target=target)
+    flat = ts.reshape(B * H, N, 3)
+    store["chamfer"] = losses.chamfer(flat, tt[None]).numpy()                       # losses.py:4-10
+    box = torch.tensor([[-2.6, -1.2], [0.4, 1.9]], dtype=torch.float32)
+    store["target_box"] = box.numpy()
+    store["box_loss"] = losses.box_loss(flat, box).numpy()                           # losses.py:26-35
+    for kind in ("rope", "cloth", "granular"):
+        fn = getattr(losses, kind + "_penalty")
+        store[kind + "_penalty"] = fn(ts, ta, tc, sim_real_ratio=10.0).numpy()       # losses.py:37-92
+    bbox = np.array([[-0.45, 0.0], [-0.25, 0.45]]) * 10.0                             # plan.py:170-174 (rope.yaml bbox)
+    store["bbox"] = bbox
+    for err_name, err in (("chamfer", partial(losses.chamfer, y=tt[None])), ("box", partial(losses.box_loss, target=box))):
+        for kind in ("rope", "cloth", "granular"):
+            pen = partial(getattr(losses, kind + "_penalty"), sim_real_ratio=10.0)
+            out = quiet(running_cost, ts, ta, tc, error_func=err, penalty_func=pen, bbox=bbox)
+            store[f"reward::{err_name}::{kind}"] = out["reward_seqs"].numpy()
+    # mean_chamfer (losses.py:12-24): masked, per-pair
+    pm = rng.uniform(size=(B, N)) > 0.2
+    rm = rng.uniform(size=(B, N)) > 0.3
+    real = (state[:, 0] + rng.normal(0, 0.05, (B, N, 3))).astype(np.float32)
+    store.update(mc_pred=state[:, 1], mc_real=real, mc_pred_mask=pm, mc_real_mask=rm)
+    store["mean_chamfer"] = losses.mean_chamfer(torch.from_numpy(state[:, 1]), torch.from_numpy(real),
+                                                torch.from_numpy(pm), torch.from_numpy(rm))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: -> {os.path.getsize(path)/1e6:.2f} MB; sample rewards {store['reward::chamfer::rope'][:3]}")
+
+
+if __name__ == "__main__" and "--costs" in sys.argv:
+    gen_cost_cases("costs")

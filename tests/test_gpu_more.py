@@ -240,3 +240,46 @@ def test_empty_and_degenerate_graphs(ag, O, dev):
         assert np.array_equal(r, np.arange(6)) and np.array_equal(s, np.arange(6))
     Rr, Rs = el.to_dense()
     assert Rr.shape == (2, 6, 6)
+
+
+# ------------------------------------------------------------------------------------------------- cost functions (§8(f) 1)
+COST_TOL = 2e-5
+
+
+def test_costs_vs_reference_golden(ag, dev):
+    from functools import partial
+    from helpers import load_golden
+    g = load_golden("costs")
+    t = lambda k: torch.from_numpy(np.asarray(g[k])).to(dev)
+    B, H, N, _ = g["state"].shape
+    flat = t("state").reshape(B * H, N, 3)
+    assert np.abs(ag.chamfer(flat, t("target")[None]).cpu().numpy() - g["chamfer"]).max() < COST_TOL
+    assert np.abs(ag.box_loss(flat, t("target_box")).cpu().numpy() - g["box_loss"]).max() < COST_TOL
+    for kind in ("rope", "cloth", "granular"):
+        got = getattr(ag, kind + "_penalty")(t("state"), t("action"), t("state_cur"), sim_real_ratio=10.0)
+        assert np.abs(got.cpu().numpy() - g[kind + "_penalty"]).max() < COST_TOL, kind
+    mc = ag.mean_chamfer(t("mc_pred"), t("mc_real"), t("mc_pred_mask"), t("mc_real_mask"))
+    assert mc.dtype == np.float64 and np.abs(mc - g["mean_chamfer"]).max() < COST_TOL
+    for err_name in ("chamfer", "box"):
+        err = partial(ag.chamfer, y=t("target")[None]) if err_name == "chamfer" else partial(ag.box_loss, target=t("target_box"))
+        for kind in ("rope", "cloth", "granular"):
+            pen = partial(getattr(ag, kind + "_penalty"), sim_real_ratio=10.0)
+            r = ag.running_cost(t("state"), t("action"), t("state_cur"), error_func=err, penalty_func=pen, bbox=g["bbox"])
+            want = g[f"reward::{err_name}::{kind}"]
+            assert np.abs(r["reward_seqs"].cpu().numpy() - want).max() < 5e-5 * max(1.0, np.abs(want).max()), (err_name, kind)
+
+
+def test_chamfer_full_size_vs_oracle(ag, dev):
+    """BASELINE-size clouds (2025 predicted x 3000 target points): oracle on 3 rows; identity and symmetry properties."""
+    from oracle import costs_oracle as Cc
+    rng = np.random.default_rng(31)
+    x = rng.normal(0, 1, (5, 2025, 3)).astype(np.float32)
+    y = rng.normal(0.2, 1, (1, 3000, 3)).astype(np.float32)
+    got = ag.chamfer(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)).cpu().numpy()
+    want = Cc.chamfer(x[:3], y)
+    assert np.abs(got[:3] - want).max() < COST_TOL
+    same = ag.chamfer(torch.from_numpy(x).to(dev), torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.all(same == 0.0)                                         # chamfer(x, x) == 0 exactly
+    xy = ag.chamfer(torch.from_numpy(x[:1]).to(dev), torch.from_numpy(y).to(dev))
+    yx = ag.chamfer(torch.from_numpy(y).to(dev), torch.from_numpy(x[:1]).to(dev))
+    assert abs(float(xy[0]) - float(yx[0])) < 1e-6                     # symmetric up to the order of the two means

@@ -71,3 +71,29 @@ def test_overflow_raises_like_reference():
     with pytest.raises(Exception, match="Exceeds max dims"):
         O.dynamics(W, int(g["pstep"]), g["state0"], g["action"], task)
     assert bytes(g["expected_exception"]).decode() == "Exceeds max dims"
+
+
+# ------------------------------------------------------------------------------------------------- cost functions
+COST_TOL = 2e-5
+
+
+def test_costs_losses_vs_reference():
+    from functools import partial
+    from oracle import costs_oracle as C
+    g = load_golden("costs")
+    B, H, N, _ = g["state"].shape
+    flat = g["state"].reshape(B * H, N, 3)
+    assert np.abs(C.chamfer(flat, g["target"][None]) - g["chamfer"]).max() < COST_TOL
+    assert np.abs(C.box_loss(flat, g["target_box"]) - g["box_loss"]).max() < COST_TOL
+    for kind in ("rope", "cloth", "granular"):
+        got = getattr(C, kind + "_penalty")(g["state"], g["action"], g["state_cur"], 10.0)
+        assert np.abs(got - g[kind + "_penalty"]).max() < COST_TOL, kind
+    mc = C.mean_chamfer(g["mc_pred"], g["mc_real"], g["mc_pred_mask"], g["mc_real_mask"])
+    assert np.abs(mc - g["mean_chamfer"]).max() < COST_TOL
+    for err_name in ("chamfer", "box"):
+        err = partial(C.chamfer, y=g["target"][None]) if err_name == "chamfer" else partial(C.box_loss, target=g["target_box"])
+        for kind in ("rope", "cloth", "granular"):
+            pen = partial(getattr(C, kind + "_penalty"), sim_real_ratio=10.0)
+            r = C.running_cost(g["state"], g["action"], g["state_cur"], err, pen, g["bbox"])
+            want = g[f"reward::{err_name}::{kind}"]
+            assert np.abs(r - want).max() < 5e-5 * max(1.0, np.abs(want).max()), (err_name, kind)
