@@ -8,7 +8,8 @@
 Workload (BASELINE.json configs[3]): cloth, 1024 MPC candidates x 20 rollout steps
 (2 look-ahead steps x action_repeat 10) x 2025 object particles + 1 gripper particle, graph rebuilt every
 step, random-init weights, synthetic jittered 45x45 cloth.  One "step" of this bench = one dynamics() call over
-the whole candidate batch + per-candidate cost (+ RCCL all-gather of the costs when N > 1).
+the whole candidate batch + the planner's running_cost (chamfer to a target cloud, cloth penalty, bbox penalty)
+(+ RCCL all-reduce(MAX) of two scalars and all-gather of the per-candidate rewards when N > 1).
 Candidates are independent, so they are sharded over ranks (STRONG scaling: the 1024-candidate batch is fixed);
 the only collective is the all-gather of B/N fp32 costs per rank.
 """
@@ -131,7 +132,12 @@ def main():
     lo, hi = shard_bounds(B, world, rank)                              # contiguous shard
     a_local = actions[lo:hi].to(dev)
     state0 = torch.from_numpy(cloud).to(dev)
-    target = state0.mean(0) + torch.tensor([0.5, 0.0, 0.5], device=dev)
+    # MPC objective of the cloth task (plan.py:139-174): chamfer to a target cloud + cloth collision penalty + bbox
+    from functools import partial
+    tgt = torch.from_numpy((cloud + np.float32([0.9, 0.0, 0.6]) + rng.normal(0, 0.02, cloud.shape)).astype(np.float32)).to(dev)
+    bbox = np.array([[-0.45, 0.0], [-0.25, 0.45]]) * task["sim_real_ratio"] * 4.0
+    err_fn = partial(ag.chamfer, y=tgt[None])
+    pen_fn = partial(ag.cloth_penalty, sim_real_ratio=float(task["sim_real_ratio"]), group=True if world > 1 else None)
     eng = model.engine(dev)
     if args.chunk:
         eng.set_chunk(args.chunk)
@@ -140,8 +146,10 @@ def main():
     def one_step():
         out = ag.dynamics(state0, a_local, model, dev, ppm, _sync=False, _overflow_flag=flag)
         seq = out["state_seqs"]                                        # (b, H, N_o, 3)
-        cost = (seq[:, -1] - target).norm(dim=-1).mean(-1)             # per-candidate running cost (stand-in)
-        return all_gather_costs(cost.contiguous(), B)                  # RCCL over xGMI: B/N fp32 per rank
+        # running_cost (plan.py:27-59): the two batch-global maxima are all-reduced (MAX) when the batch is sharded
+        rew = ag.running_cost(seq, a_local, state0, error_func=err_fn, penalty_func=pen_fn, bbox=bbox,
+                              group=True if world > 1 else None)["reward_seqs"]
+        return all_gather_costs(rew.contiguous(), B)                   # RCCL over xGMI: B/N fp32 per rank
 
     def sync_all():
         if world > 1:
@@ -169,7 +177,8 @@ def main():
     # the stream they are launched on.  Profiling pins the engine to ONE stream: with two chunks sharing the GPU an
     # event-bracketed duration measures the neighbour's kernels too.
     fams = [] if args.no_kernel_profile else ["edge_enc"] if not args.profile_all else [
-        "edge_count", "edge_emit", "node_enc", "edge_enc", "mp", "node_prop", "node_final", "roll_init", "roll_update"]
+        "edge_count", "edge_emit", "node_enc", "edge_enc", "mp", "node_prop", "node_final", "roll_init", "roll_update",
+        "cost"]
     prof_steps = 1
     eng.reset_stats()
     if fams:

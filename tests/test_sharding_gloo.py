@@ -42,6 +42,9 @@ def _worker(rank, world, port, B, q):
     ok = torch.equal(full, want)                           # sharded == unsharded, bit for bit
     lo, hi = shard_bounds(B, world, rank)
     ok = ok and torch.equal(all_gather_costs(want[lo:hi], B), want)
+    # batch-global maxima of the cost functions (plan.py:37, losses.py:62) under sharding
+    from adaptigraph_amd.losses import _global_max
+    ok = ok and float(_global_max(want[lo:hi], True)) == float(want.max())
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
