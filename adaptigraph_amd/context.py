@@ -51,6 +51,10 @@ class Engine:
             raise RuntimeError(msg)
         self.pstep = pstep
         self._weights_key = None
+        self.precision = "fp32"
+        import os
+        if os.environ.get("AG_PRECISION", "fp32") != "fp32":
+            self.set_precision(os.environ["AG_PRECISION"])
 
     def close(self):
         if self._ctx:
@@ -84,6 +88,11 @@ class Engine:
                 host.append(sd[base + suffix].detach().to("cpu", torch.float32).contiguous())
         arr = (C.c_void_p * len(host))(*[t.data_ptr() for t in host])
         self.check(self.lib.ag_ctx_load_weights(self._ctx, arr, len(host)))
+
+    def set_precision(self, mode):
+        """'fp32' (default, exact v_mfma_f32) or 'bf16x3' (3-way bf16 split on the bf16 matrix pipe, fp32-grade accuracy)."""
+        self.check(self.lib.ag_ctx_set_precision(self._ctx, {"fp32": 0, "bf16x3": 1}[mode]))
+        self.precision = mode
 
     def set_chunk(self, n):
         self.check(self.lib.ag_ctx_set_chunk(self._ctx, int(n)))

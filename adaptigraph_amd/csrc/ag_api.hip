@@ -43,6 +43,8 @@ struct ag_ctx {
     ag_dims dims{};
     std::string err;
     float* d_w = nullptr;
+    float* d_wb3 = nullptr;      // bf16x3 weight image (58 phases of 30,720 B)
+    int precision = 0;           // 0: exact fp32 MFMA (default), 1: bf16x3 split on the bf16 matrix pipe
     bool have_w = false;
     Slab slab;
     int chunk = 0;
@@ -139,6 +141,56 @@ void pack_first(float* dst, const float* W, int in_dim, const float* bias, int n
                         else if (k == in_dim) v = bias[m];
                     }
                     dst[((size_t)(q * 5 + mb) * 64 + lane) * 4 + e] = v;
+                }
+}
+
+// ---- bf16x3 weight image (see ag_mlp.hip): every weight is split exactly into three bf16 pieces
+uint16_t bf16_rn(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf16_f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+void split3(float w, uint16_t out[3]) {
+    out[0] = bf16_rn(w);
+    const float r = w - bf16_f(out[0]);
+    out[1] = bf16_rn(r);
+    const float q = r - bf16_f(out[1]);
+    out[2] = bf16_rn(q);
+}
+// image index (uint16 units) of element j of lane `lane`, part `part`, m-block mb, k-step ks (MB m-blocks per k-step)
+size_t b3_idx(int ks, int MB, int mb, int part, int lane, int j) { return ((((size_t)ks * MB + mb) * 3 + part) * 64 + lane) * 8 + j; }
+void pack_layer_b3(uint16_t* dst, const float* W, int ld, int col0, int out_dim, int in_dim, const float* bias, int MB) {
+    for (int ks = 0; ks < 10; ++ks)                        // k-step ks = 2*tile + u
+        for (int mb = 0; mb < MB; ++mb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int t = ks >> 1, u = ks & 1, h = lane >> 5;
+                    const int k = 32 * t + 16 * u + (j & 3) + 8 * (j >> 2) + 4 * h, m = 32 * mb + (lane & 31);
+                    float v = 0.f;
+                    if (m < out_dim) {
+                        if (k < in_dim) v = W[(size_t)m * ld + col0 + k];
+                        else if (k == ONE_F && bias) v = bias[m];
+                    }
+                    uint16_t p3[3];
+                    split3(v, p3);
+                    for (int part = 0; part < 3; ++part) dst[b3_idx(ks, MB, mb, part, lane, j)] = p3[part];
+                }
+}
+void pack_first_b3(uint16_t* dst, const float* W, int in_dim, const float* bias) {
+    for (int ks = 0; ks < 2; ++ks)
+        for (int mb = 0; mb < 5; ++mb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * ks + 8 * (lane >> 5) + j, m = 32 * mb + (lane & 31);
+                    float v = 0.f;
+                    if (m < NF) {
+                        if (k < in_dim) v = W[(size_t)m * in_dim + k];
+                        else if (k == in_dim) v = bias[m];
+                    }
+                    uint16_t p3[3];
+                    split3(v, p3);
+                    for (int part = 0; part < 3; ++part) dst[b3_idx(ks, 5, mb, part, lane, j)] = p3[part];
                 }
 }
 
@@ -250,6 +302,35 @@ int run_model(ag_ctx* c, const GraphBufs& g, float* pred_pos, float* pred_motion
     return AG_OK;
 }
 
+// C rows of the two kinds of self-loop edge (object: attrs 1,0; tool: attrs 0,1), through the real edge chain of the
+// ACTIVE precision mode on a 2-particle, 2-edge graph {(0,0),(1,1)} - bitwise what k_edge_enc produces for such edges.
+int compute_self_rows(ag_ctx* c) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_cself) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_cself), 256 * NFP * 4));
+    struct Mini { float node_in[2 * NODE_IN]; float feat12[2 * F12]; float group[2]; int recv[2]; int send[2]; int n_edges; int pad; } h{};
+    h.node_in[0] = 1.f; h.node_in[6] = 1.f;                         // object particle
+    h.node_in[NODE_IN + 1] = 1.f; h.node_in[NODE_IN + 6] = 1.f;     // tool particle
+    h.group[0] = 1.f;
+    h.recv[0] = 0; h.recv[1] = 1; h.send[0] = 0; h.send[1] = 1; h.n_edges = 2;
+    char* d = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), sizeof(Mini)));
+    HIPCHK(c, hipMemcpy(d, &h, sizeof(Mini), hipMemcpyHostToDevice));
+    GraphBufs g{};
+    g.node_in = reinterpret_cast<float*>(d + offsetof(Mini, node_in));
+    g.feat12 = reinterpret_cast<float*>(d + offsetof(Mini, feat12));
+    g.group = reinterpret_cast<float*>(d + offsetof(Mini, group));
+    g.recv = reinterpret_cast<int*>(d + offsetof(Mini, recv));
+    g.send = reinterpret_cast<int*>(d + offsetof(Mini, send));
+    g.n_edges = reinterpret_cast<int*>(d + offsetof(Mini, n_edges));
+    g.C = c->d_cself; g.B = 1; g.N = 2; g.n_p = 1; g.n_inst = 1; g.edge_cap = 2; g.c_cap = 256;
+    g.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
+    hipError_t e = launch_edge_enc(c->d_w, g, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, AG_ERR_HIP, "self-loop C rows: %s", hipGetErrorString(e));
+    return AG_OK;
+}
+
 int check_topk(ag_ctx* c, int N, int topk) {
     if (N < 1 || topk < 1) return fail(c, AG_ERR_INVALID, "N and topk must be >= 1");
     if ((size_t)N > edge_build_max_particles()) return fail(c, AG_ERR_UNSUPPORTED, "N=%d exceeds the LDS-resident edge builder limit %zu", N, edge_build_max_particles());
@@ -293,12 +374,21 @@ int ag_ctx_destroy(ag_ctx* c) {
         if (c->aux_stream[i]) (void)hipStreamDestroy(c->aux_stream[i]);
     }
     if (c->d_w) (void)hipFree(c->d_w);
+    if (c->d_wb3) (void)hipFree(c->d_wb3);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
     if (c->d_cself) (void)hipFree(c->d_cself);
     if (c->d_repeat) (void)hipFree(c->d_repeat);
     if (c->slab.base) (void)hipFree(c->slab.base);
     delete c;
     return AG_OK;
+}
+
+int ag_ctx_set_precision(ag_ctx* c, int32_t mode) {
+    if (!c) return AG_ERR_INVALID;
+    if (mode != 0 && mode != 1) return fail(c, AG_ERR_INVALID, "precision mode must be 0 (fp32) or 1 (bf16x3)");
+    if (mode == c->precision) return AG_OK;
+    c->precision = mode;
+    return c->have_w ? compute_self_rows(c) : AG_OK;
 }
 
 int ag_ctx_set_chunk(ag_ctx* c, int32_t n) {
@@ -334,33 +424,30 @@ int ag_ctx_load_weights(ag_ctx* c, const float* const* t, int32_t n) {
     pack_layer(b + WL::P_P2, t[20], NF, 0, 3, NF, t[21], 1);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(c->d_w, b, blob.size() * 4, hipMemcpyHostToDevice));
-    // C rows of the two kinds of self-loop edge (object: attrs 1,0; tool: attrs 0,1), through the real edge chain on
-    // a 2-particle, 2-edge graph {(0,0),(1,1)} - bitwise what k_edge_enc would produce for any such edge.
+    // bf16x3 image (opt-in precision mode, ag_ctx_set_precision)
     {
-        if (!c->d_cself) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_cself), 256 * NFP * 4));
-        struct Mini { float node_in[2 * NODE_IN]; float feat12[2 * F12]; float group[2]; int recv[2]; int send[2]; int n_edges; int pad; } h{};
-        h.node_in[0] = 1.f; h.node_in[6] = 1.f;                         // object particle
-        h.node_in[NODE_IN + 1] = 1.f; h.node_in[NODE_IN + 6] = 1.f;     // tool particle
-        h.group[0] = 1.f;
-        h.recv[0] = 0; h.recv[1] = 1; h.send[0] = 0; h.send[1] = 1; h.n_edges = 2;
-        char* d = nullptr;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), sizeof(Mini)));
-        HIPCHK(c, hipMemcpy(d, &h, sizeof(Mini), hipMemcpyHostToDevice));
-        GraphBufs g{};
-        g.node_in = reinterpret_cast<float*>(d + offsetof(Mini, node_in));
-        g.feat12 = reinterpret_cast<float*>(d + offsetof(Mini, feat12));
-        g.group = reinterpret_cast<float*>(d + offsetof(Mini, group));
-        g.recv = reinterpret_cast<int*>(d + offsetof(Mini, recv));
-        g.send = reinterpret_cast<int*>(d + offsetof(Mini, send));
-        g.n_edges = reinterpret_cast<int*>(d + offsetof(Mini, n_edges));
-        g.C = c->d_cself; g.B = 1; g.N = 2; g.n_p = 1; g.n_inst = 1; g.edge_cap = 2; g.c_cap = 256;
-        hipError_t e = launch_edge_enc(c->d_w, g, nullptr);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        (void)hipFree(d);
-        if (e != hipSuccess) return fail(c, AG_ERR_HIP, "self-loop C rows: %s", hipGetErrorString(e));
+        std::vector<uint16_t> img((size_t)B3_PHASES * B3_PHASE_BYTES / 2, 0);
+        auto ph = [&](int phase) { return img.data() + (size_t)phase * B3_PHASE_BYTES / 2; };
+        // phase indices = WLB in ag_mlp.hip
+        pack_first_b3(ph(0), t[6], REL_DIM, t[7]);
+        pack_layer_b3(ph(1), t[8], NF, 0, NF, NF, t[9], 5);
+        pack_layer_b3(ph(6), t[10], NF, 0, NF, NF, t[11], 5);
+        pack_layer_b3(ph(11), t[14], 3 * NF, 0, NF, NF, t[15], 5);
+        pack_first_b3(ph(16), t[0], IN_DIM, t[1]);
+        pack_layer_b3(ph(17), t[2], NF, 0, NF, NF, t[3], 5);
+        pack_layer_b3(ph(22), t[4], NF, 0, NF, NF, t[5], 5);
+        pack_layer_b3(ph(27), t[12], 2 * NF, 0, NF, NF, t[13], 5);
+        pack_layer_b3(ph(32), t[14], 3 * NF, NF, NF, NF, nullptr, 5);
+        pack_layer_b3(ph(37), t[14], 3 * NF, 2 * NF, NF, NF, nullptr, 5);
+        pack_layer_b3(ph(42), t[12], 2 * NF, NF, NF, NF, nullptr, 5);
+        pack_layer_b3(ph(47), t[16], NF, 0, NF, NF, t[17], 5);
+        pack_layer_b3(ph(52), t[18], NF, 0, NF, NF, t[19], 5);
+        pack_layer_b3(ph(57), t[20], NF, 0, 3, NF, t[21], 1);
+        if (!c->d_wb3) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wb3), img.size() * 2));
+        HIPCHK(c, hipMemcpy(c->d_wb3, img.data(), img.size() * 2, hipMemcpyHostToDevice));
     }
     c->have_w = true;
-    return AG_OK;
+    return compute_self_rows(c);
 }
 
 int ag_build_edges(ag_ctx* c, void* stream, const float* d_pos, const uint8_t* d_mask, const uint8_t* d_tool,
@@ -416,6 +503,7 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
         const int nb = std::min(Bc, B - b0);
         GraphBufs g = w.g;
         g.B = nb; g.n_p = n_p;
+        g.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
         g.group = const_cast<float*>(d_group) + (size_t)b0 * N * n_inst;
         g.recv = d_recv + (size_t)b0 * edge_cap; g.send = d_send + (size_t)b0 * edge_cap;
         g.row_ptr = d_row_ptr + (size_t)b0 * (N + 1); g.n_edges = d_n_edges + b0;
@@ -500,6 +588,7 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         c->prof_stream = cs;
         GraphBufs g = w.g;
         g.B = nb; g.n_p = p->N_o;
+        g.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
         static const bool dedupe = !(getenv("AG_NO_SELF_DEDUPE") && atoi(getenv("AG_NO_SELF_DEDUPE")));
         if (dedupe) {
             g.c_self = c->d_cself; g.ns_edge = w.ns_edge; g.n_ns = w.n_ns;

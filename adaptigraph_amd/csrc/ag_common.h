@@ -112,7 +112,10 @@ struct GraphBufs {
     const float* c_self;                   // (2, NFP) or null
     long self_row;                         // row of C where c_self[0..1] were copied (k_mp reads them from there)
     const int* ns_edge; const int* n_ns;   // (B,edge_cap), (B,) or null
+    const float* wb3;                      // bf16x3 weight image: non-null selects the bf16x3 chains (ag_mlp.hip)
 };
+constexpr int B3_PHASE_BYTES = 2 * 5 * 3 * 64 * 16;   // 30,720
+constexpr int B3_PHASES = 58;
 inline long cls_rows(int N_o, int M, int B) { return 2L * N_o + (long)B * M; }
 // row0/nrows select a slice of the class table when g.cls_on, else all B*N rows are encoded
 hipError_t launch_node_enc(const float* wblob, const GraphBufs& g, long row0, long nrows, hipStream_t st);

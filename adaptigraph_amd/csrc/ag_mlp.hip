@@ -252,6 +252,7 @@ struct GDev {
     const float* c_eff; const float* c_P;
     long row0, nrows;          // k_node_enc: slice of rows to encode
     const int* ns_edge; const int* n_ns;   // k_edge_enc: non-self-loop edge list (null = every edge)
+    const float* wb3;                      // bf16x3 weight image (null = exact fp32 mode)
     unsigned long long* dbg;   // diagnostic build of the clock probe only: 4 stamps per workgroup, never read by kernels
 };
 
@@ -429,6 +430,262 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     }
 }
 
+
+// =====================================================================================================================
+// "bf16x3" mode (opt-in, ag_ctx_set_precision): the same chains on the bf16 matrix pipe with fp32-grade accuracy.
+// Every fp32 operand is split exactly into three bf16 pieces (x = xh + xm + xl, 8+8+8 mantissa bits); a product is
+// rebuilt from the six partial products whose weight is >= 2^-24 of it (xl*wh, xh*wl, xm*wm, xm*wh, xh*wm, xh*wh -
+// bf16 x bf16 is exact in fp32), accumulated in the fp32 MFMA accumulator, smallest first.  Dropped terms are
+// <= 2^-24 relative, the size of an fp32 rounding.  v_mfma_f32_32x32x16_bf16 runs 16x the fp32-MFMA FLOP rate, so six
+// of them per fp32-equivalent step is ~2.7x faster.  The accumulator layout is the same as for the fp32 MFMA (C/D
+// maps are dtype-independent on gfx950), so the register-chaining scheme carries over: K-step (tile t, half u) takes
+// accumulator registers 8u..8u+7 of tile t, i.e. features 32t + 16u + (j&3) + 8(j>>2) + 4h for element j of lane-half
+// h - again folded into the host-side weight image.
+// Weights: [phase][k-step in phase (2)][m-block][part h/m/l][lane][8 bf16]; one phase = one 32-feature tile of K
+// = 30,720 B; a 160-wide layer = 5 phases; the 3-output head = 1 phase of 10 k-steps; first layers = 1 phase.
+// =====================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int PH_FLOATS = 2 * 5 * 3 * 64 * 4;         // one staged phase, in floats (30,720 B)
+struct WLB {                                          // phase index of every layer in the bf16x3 weight image
+    static constexpr int E_L1 = 0, E_L2 = 1, E_L3 = 6, E_W1 = 11;
+    static constexpr int N_L1 = 16, N_L2 = 17, N_L3 = 22, N_WA = 27, N_W2 = 32, N_W3 = 37;
+    static constexpr int P_WB = 42, P_P0 = 47, P_P1 = 52, P_P2 = 57, TOTAL = 58;
+};
+
+// exact 3-way split of 8 fp32 values into bf16 pieces (round-to-nearest at every level; remainders are exact)
+__device__ __forceinline__ void split8(const float* x, bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 hi = (__bf16)x[i];
+        const float r = x[i] - (float)hi;
+        const __bf16 mi = (__bf16)r;
+        const float q = r - (float)mi;
+        h[i] = hi; m[i] = mi; l[i] = (__bf16)q;
+    }
+}
+// NK k-steps of one phase: B pieces in bh/bm/bl[NK]; A pieces read from the LDS image [ks][mb][part][lane]
+template <int NK, int MB>
+__device__ __forceinline__ void mma_b3(const float* wl, const bf16x8* bh, const bf16x8* bm, const bf16x8* bl,
+                                       f32x16* acc, int lane) {
+    const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const bf16x8 ah = w[((ks * MB + mb) * 3 + 0) * 64 + lane];
+            const bf16x8 am = w[((ks * MB + mb) * 3 + 1) * 64 + lane];
+            const bf16x8 al = w[((ks * MB + mb) * 3 + 2) * 64 + lane];
+            f32x16 c = acc[mb];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[ks], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], c, 0, 0, 0);
+            acc[mb] = c;
+        }
+}
+// One 160-wide layer in bf16x3: 5 phases, phase p consumes accumulator tile p of `in`.  Precondition: phase 0 of the
+// layer is in LDS buffer `cur` and a barrier has passed.  Each phase runs with the next phase (or `next`, the first
+// phase of the following layer) streaming global -> registers -> the other buffer.  `cur` flips once per phase.
+template <bool HAS_NEXT, bool ZERO = true>
+__device__ __forceinline__ void layer160_b3(float* lds, int& cur, const float* __restrict__ w,
+                                            const float* __restrict__ next, const Act& in, Act& out, int tid, int lane) {
+    if (ZERO) zero(out);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const bool more = p < 4 || HAS_NEXT;
+        const float* nsrc = p < 4 ? w + (p + 1) * PH_FLOATS : next;
+        float* other = lds + (cur ^ 1) * PH_FLOATS;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                       // one k-step at a time: 12 VGPRs of bf16 pieces and half a
+            Stager<PH_FLOATS / 2> s;                        // phase (16 VGPRs) of staging in flight
+            if (more) s.load(nsrc + u * (PH_FLOATS / 2), tid);
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = in.t[p][8 * u + j];
+            bf16x8 bh, bm, bl;
+            split8(x, bh, bm, bl);
+            mma_b3<1, 5>(lds + cur * PH_FLOATS + u * (5 * 3 * 64 * 4), &bh, &bm, &bl, out.t, lane);
+            if (more) s.store(other + u * (PH_FLOATS / 2), tid);
+        }
+        if (more) {
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+}
+// first layer from NF per-lane input features (zero beyond NF): k-step u, lane-half h, element j <-> feature 16u+8h+j
+template <int NK, int NF>
+__device__ __forceinline__ void first_b3(const float* wl, const float* f, f32x16* acc, int lane) {
+    const bool hi = lane >= 32;
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float lo_v = 16 * u + j < NF ? f[(16 * u + j) < NF ? (16 * u + j) : 0] : 0.0f;
+            const float hi_v = 16 * u + 8 + j < NF ? f[(16 * u + 8 + j) < NF ? (16 * u + 8 + j) : 0] : 0.0f;
+            x[j] = hi ? hi_v : lo_v;
+        }
+        bf16x8 bh, bm, bl;
+        split8(x, bh, bm, bl);
+        mma_b3<1, 5>(wl + u * (5 * 3 * 64 * 4), &bh, &bm, &bl, acc, lane);
+    }
+}
+
+__global__ __launch_bounds__(WG, 2) void k_edge_enc_b3(GDev g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * PH_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = (int)(blockIdx.x % (unsigned)g.B);
+    const int e0 = (int)(blockIdx.x / (unsigned)g.B) * WG_ROWS;
+    const int ne = g.n_ns ? g.n_ns[b] : g.n_edges[b];
+    if (e0 >= ne) return;
+    const float* W = g.wb3;
+    stage_now<PH_FLOATS>(lds, W + WLB::E_L1 * PH_FLOATS, tid);
+    int cur = 0;
+    Stager<PH_FLOATS> sn;
+    sn.load(W + WLB::E_L2 * PH_FLOATS, tid);
+
+    const int t = e0 + wave * 32 + (lane & 31);
+    const bool valid = t < ne;
+    const int el = g.ns_edge ? g.ns_edge[(long)b * g.edge_cap + (valid ? t : 0)] : t;
+    const int elc = valid ? el : (g.ns_edge ? el : 0);
+    const int r = g.recv[(long)b * g.edge_cap + elc], s = g.send[(long)b * g.edge_cap + elc];
+    const long pr = (long)b * g.N + r, ps = (long)b * g.N + s;
+    float f[18];
+    {
+        const float* nr = g.node_in + pr * NODE_IN; const float* nsnd = g.node_in + ps * NODE_IN;
+        f[0] = nr[0]; f[1] = nr[1]; f[2] = nsnd[0]; f[3] = nsnd[1];
+        float gd = 0.0f;
+        for (int k = 0; k < g.n_inst; ++k) gd += fabsf(g.group[pr * g.n_inst + k] - g.group[ps * g.n_inst + k]);
+        f[4] = gd;
+        const f32x4* fr = reinterpret_cast<const f32x4*>(g.feat12 + pr * F12);
+        const f32x4* fs = reinterpret_cast<const f32x4*>(g.feat12 + ps * F12);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const f32x4 a = fr[q], c = fs[q];
+            f[5 + 4 * q + 0] = a[0] - c[0]; f[5 + 4 * q + 1] = a[1] - c[1];
+            f[5 + 4 * q + 2] = a[2] - c[2]; f[5 + 4 * q + 3] = a[3] - c[3];
+        }
+        f[17] = 1.0f;
+    }
+    Act x, y;
+    zero(y);
+    first_b3<2, 18>(lds + cur * PH_FLOATS, f, y.t, lane);
+    sn.store(lds + (cur ^ 1) * PH_FLOATS, tid);
+    __syncthreads();
+    cur ^= 1;
+    relu_one(y, lane);
+    layer160_b3<true>(lds, cur, W + WLB::E_L2 * PH_FLOATS, W + WLB::E_L3 * PH_FLOATS, y, x, tid, lane);
+    relu_one(x, lane);
+    layer160_b3<true>(lds, cur, W + WLB::E_L3 * PH_FLOATS, W + WLB::E_W1 * PH_FLOATS, x, y, tid, lane);
+    relu_one(y, lane);
+    layer160_b3<false>(lds, cur, W + WLB::E_W1 * PH_FLOATS, nullptr, y, x, tid, lane);
+    store_rows(x, g.C, (long)b * g.c_cap + el, lane, valid);
+}
+
+__global__ __launch_bounds__(WG, 2) void k_node_enc_b3(GDev g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * PH_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long rend = g.row0 + g.nrows;
+    const long row = g.row0 + (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
+    const bool valid = row < rend;
+    const long rowc = valid ? row : rend - 1;
+    const float* W = g.wb3;
+    stage_now<PH_FLOATS>(lds, W + WLB::N_L1 * PH_FLOATS, tid);
+    int cur = 0;
+    Stager<PH_FLOATS> sn;
+    sn.load(W + WLB::N_L2 * PH_FLOATS, tid);
+    float f[8];
+    {
+        const f32x4* p = reinterpret_cast<const f32x4*>(g.node_in + rowc * NODE_IN);
+        const f32x4 a = p[0], c = p[1];
+        f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = c[0]; f[5] = c[1]; f[6] = c[2]; f[7] = c[3];
+    }
+    Act x, y;
+    zero(y);
+    first_b3<1, 8>(lds + cur * PH_FLOATS, f, y.t, lane);
+    sn.store(lds + (cur ^ 1) * PH_FLOATS, tid);
+    __syncthreads();
+    cur ^= 1;
+    relu_one(y, lane);
+    layer160_b3<true>(lds, cur, W + WLB::N_L2 * PH_FLOATS, W + WLB::N_L3 * PH_FLOATS, y, x, tid, lane);
+    relu_one(x, lane);
+    layer160_b3<true>(lds, cur, W + WLB::N_L3 * PH_FLOATS, W + WLB::N_WA * PH_FLOATS, x, y, tid, lane);
+    relu_one(y, lane);
+    store_rows(y, g.eff, row, lane, valid);
+    layer160_b3<true>(lds, cur, W + WLB::N_WA * PH_FLOATS, W + WLB::N_W2 * PH_FLOATS, y, x, tid, lane);
+    store_rows(x, g.P, row, lane, valid);
+    layer160_b3<true>(lds, cur, W + WLB::N_W2 * PH_FLOATS, W + WLB::N_W3 * PH_FLOATS, y, x, tid, lane);
+    store_rows(x, g.U, row, lane, valid);
+    layer160_b3<false>(lds, cur, W + WLB::N_W3 * PH_FLOATS, nullptr, y, x, tid, lane);
+    store_rows(x, g.V, row, lane, valid);
+}
+
+template <bool LAST>
+__global__ __launch_bounds__(WG, 2) void k_node_prop_b3(GDev g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * PH_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long nrows = (long)g.B * g.N;
+    const long row = (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
+    const bool valid = row < nrows;
+    const long rowc = valid ? row : nrows - 1;
+    const float* W = g.wb3;
+    stage_now<PH_FLOATS>(lds, W + WLB::P_WB * PH_FLOATS, tid);
+    int cur = 0;
+    Act x, y;
+    const int pb = (int)(rowc / g.N), pi = (int)(rowc - (long)pb * g.N);
+    const long crow = g.cls_on ? cls_row(g, pb, pi) : rowc;
+    const bool ceff = g.cls_on && g.first_round;
+    load_rows(x, g.agg, rowc, lane);
+    load_rows(y, g.cls_on ? g.c_P : g.P, crow, lane);
+    add_rows_part<0, 2>(y, ceff ? g.c_eff : g.eff, ceff ? crow : rowc, lane);
+    materialize(y);
+    add_rows_part<2, 5>(y, ceff ? g.c_eff : g.eff, (ceff ? crow : rowc) + pin_after(y), lane);
+    layer160_b3<true, false>(lds, cur, W + WLB::P_WB * PH_FLOATS, W + (LAST ? WLB::P_P0 : WLB::N_W2) * PH_FLOATS, x, y,
+                             tid, lane);
+    relu_one(y, lane);
+    if (!LAST) {
+        store_rows(y, g.eff, row, lane, valid);
+        layer160_b3<true>(lds, cur, W + WLB::N_W2 * PH_FLOATS, W + WLB::N_W3 * PH_FLOATS, y, x, tid, lane);
+        store_rows(x, g.U, row, lane, valid);
+        layer160_b3<false>(lds, cur, W + WLB::N_W3 * PH_FLOATS, nullptr, y, x, tid, lane);
+        store_rows(x, g.V, row, lane, valid);
+    } else {
+        layer160_b3<true>(lds, cur, W + WLB::P_P0 * PH_FLOATS, W + WLB::P_P1 * PH_FLOATS, y, x, tid, lane);
+        relu_one(x, lane);
+        layer160_b3<true>(lds, cur, W + WLB::P_P1 * PH_FLOATS, W + WLB::P_P2 * PH_FLOATS, x, y, tid, lane);
+        relu_one(y, lane);
+        f32x16 m[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[0][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {                       // head: 10 k-steps, one m-block, all in one phase
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float xx[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xx[j] = y.t[t][8 * u + j];
+                bf16x8 bh, bm, bl;
+                split8(xx, bh, bm, bl);
+                mma_b3<1, 1>(lds + cur * PH_FLOATS + (2 * t + u) * (3 * 64 * 4), &bh, &bm, &bl, m, lane);
+            }
+        }
+        const int b = pb, i = pi;
+        if (valid && lane < 32 && i < g.n_p) {
+            const float* curp = g.feat12 + rowc * F12 + 9;
+            const long o = ((long)b * g.n_p + i) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float mo = m[0][c];
+                g.pred_motion[o + c] = mo;
+                g.pred_pos[o + c] = curp[c] + fminf(fmaxf(mo, -g.clamp), g.clamp);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static GDev to_dev(const float* w, const GraphBufs& g) {
     GDev d;
@@ -439,6 +696,7 @@ static GDev to_dev(const float* w, const GraphBufs& g) {
     d.cls_on = g.cls_on; d.N_o = g.N_o; d.M = g.M; d.first_round = 0; d.vmask = g.vmask; d.c_eff = g.c_eff; d.c_P = g.c_P;
     d.row0 = 0; d.nrows = (long)g.B * g.N;
     d.ns_edge = g.ns_edge; d.n_ns = g.n_ns;
+    d.wb3 = g.wb3;
     d.dbg = nullptr;
     return d;
 }
@@ -457,7 +715,8 @@ hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
         (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 32, st);
         d.dbg = dbg;
     }
-    hipLaunchKernelGGL(k_edge_enc, dim3(nwg), dim3(WG), 0, st, d);
+    if (d.wb3) hipLaunchKernelGGL(k_edge_enc_b3, dim3(nwg), dim3(WG), 0, st, d);
+    else hipLaunchKernelGGL(k_edge_enc, dim3(nwg), dim3(WG), 0, st, d);
     if (probe_left > 0) {
         --probe_left;
         (void)hipStreamSynchronize(st);
@@ -482,13 +741,16 @@ hipError_t launch_node_enc(const float* w, const GraphBufs& g, long row0, long n
         d.row0 = row0; d.nrows = nrows;
     }
     if (d.nrows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_node_enc, dim3((unsigned)((d.nrows + WG_ROWS - 1) / WG_ROWS)), dim3(WG), 0, st, d);
+    const dim3 grid((unsigned)((d.nrows + WG_ROWS - 1) / WG_ROWS));
+    if (d.wb3) hipLaunchKernelGGL(k_node_enc_b3, grid, dim3(WG), 0, st, d);
+    else hipLaunchKernelGGL(k_node_enc, grid, dim3(WG), 0, st, d);
     return hipGetLastError();
 }
 hipError_t launch_node_prop(const float* w, const GraphBufs& g, int first_round, hipStream_t st) {
     GDev d = to_dev(w, g);
     d.first_round = first_round;
-    hipLaunchKernelGGL(k_node_prop<false>, dim3(node_grid(g)), dim3(WG), 0, st, d);
+    if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<false>, dim3(node_grid(g)), dim3(WG), 0, st, d);
+    else hipLaunchKernelGGL(k_node_prop<false>, dim3(node_grid(g)), dim3(WG), 0, st, d);
     return hipGetLastError();
 }
 hipError_t launch_node_final(const float* w, const GraphBufs& g, int first_round, float clamp, float* pred_pos,
@@ -496,7 +758,8 @@ hipError_t launch_node_final(const float* w, const GraphBufs& g, int first_round
     GDev d = to_dev(w, g);
     d.first_round = first_round;
     d.clamp = clamp; d.pred_pos = pred_pos; d.pred_motion = pred_motion;
-    hipLaunchKernelGGL(k_node_prop<true>, dim3(node_grid(g)), dim3(WG), 0, st, d);
+    if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<true>, dim3(node_grid(g)), dim3(WG), 0, st, d);
+    else hipLaunchKernelGGL(k_node_prop<true>, dim3(node_grid(g)), dim3(WG), 0, st, d);
     return hipGetLastError();
 }
 

@@ -79,13 +79,24 @@ class DynamicsPredictor(nn.Module):
             p.requires_grad_(False)
         self._engine = None
         self._uploaded_key = None
+        self._precision = None       # None: the engine default (exact fp32, or AG_PRECISION)
 
     # ------------------------------------------------------------------ engine / weights
+    def set_precision(self, mode):
+        """'fp32': exact fp32 MFMA (default).  'bf16x3': 3-way bf16 split on the bf16 matrix pipe with fp32 accumulation
+        - fp32-grade accuracy (same 1e-5 parity bar, tests/test_gpu_more.py), ~1.4x faster end to end."""
+        assert mode in ("fp32", "bf16x3")
+        self._precision = mode
+        if self._engine is not None:
+            self._engine.set_precision(mode)
+
     def engine(self, device=None):
         dev = _require_gpu(device if device is not None else self.device)
         if self._engine is None or self._engine.device != dev:
             self._engine = Engine(dev, pstep=self.model_config["pstep"], motion_clamp=float(self.motion_clamp))
             self._uploaded_key = None
+            if self._precision is not None:
+                self._engine.set_precision(self._precision)
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if key != self._uploaded_key:
             self._engine.load_state_dict_tensors(self.state_dict())

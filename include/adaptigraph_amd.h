@@ -90,6 +90,12 @@ const char* ag_last_error(const ag_ctx* ctx);
  * Synchronous (repacks on the host, copies, waits). */
 int ag_ctx_load_weights(ag_ctx* ctx, const float* const* h_tensors, int32_t n_tensors);
 
+/* Arithmetic of the MLP chains.  0 (default): exact fp32 on v_mfma_f32_32x32x2_f32.  1: "bf16x3" - every fp32 operand
+ * is split exactly into three bf16 pieces and each product is rebuilt from its six leading partial products on the
+ * bf16 matrix pipe with fp32 accumulation (error per product ~2^-24, i.e. fp32-grade; ~2.7x the fp32-MFMA rate).
+ * Edge construction is unaffected (always exact).  Re-derives the self-loop constant rows; synchronous. */
+int ag_ctx_set_precision(ag_ctx* ctx, int32_t mode);
+
 /* Tuning: candidates per launch wave of the rollout (0 = automatic). */
 int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
 

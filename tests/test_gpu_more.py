@@ -283,3 +283,41 @@ def test_chamfer_full_size_vs_oracle(ag, dev):
     xy = ag.chamfer(torch.from_numpy(x[:1]).to(dev), torch.from_numpy(y).to(dev))
     yx = ag.chamfer(torch.from_numpy(y).to(dev), torch.from_numpy(x[:1]).to(dev))
     assert abs(float(xy[0]) - float(yx[0])) < 1e-6                     # symmetric up to the order of the two means
+
+
+# ------------------------------------------------------------------------------------------------- bf16x3 precision mode
+@pytest.mark.parametrize("name,material", [("dyn_rope", "rope"), ("dyn_granular", "granular"), ("dyn_cloth", "cloth")])
+def test_bf16x3_mode_meets_the_same_bar(ag, dev, name, material):
+    """The opt-in bf16x3 arithmetic (3-way bf16 split, fp32 accumulate) against the reference's golden rollouts at the
+    SAME 1e-5 tolerance, and against the exact-fp32 mode (difference far below the tolerance)."""
+    from helpers import load_golden, task_of
+    from test_gpu_parity import _model as golden_model
+    g = load_golden(name)
+    task = task_of(g)
+    m = golden_model(ag, g, material, dev)
+    s0, a = torch.from_numpy(g["state0"]).to(dev), torch.from_numpy(g["action"]).to(dev)
+    exact = ag.dynamics(s0, a, m, dev, _ppm(task, material))["state_seqs"]
+    m.set_precision("bf16x3")
+    fast = ag.dynamics(s0, a, m, dev, _ppm(task, material))["state_seqs"]
+    m.set_precision("fp32")
+    again = ag.dynamics(s0, a, m, dev, _ppm(task, material))["state_seqs"]
+    assert torch.equal(again, exact)                                   # switching back restores the exact path bit for bit
+    err_ref = np.abs(fast.cpu().numpy() - g["state_seqs"]).max()
+    err_exact = float((fast - exact).abs().max())
+    print(f"{name}: bf16x3 vs reference {err_ref:.2e}, vs exact-fp32 mode {err_exact:.2e}")
+    assert err_ref <= POS_TOL and err_exact <= 2e-6
+
+
+def test_bf16x3_twenty_step_free_running(ag, O, dev):
+    rng = np.random.default_rng(21)
+    task = _task("granular", max_nR=20000)
+    W, m = _model(ag, O, "granular", 21, dev)
+    cloud = _grid(18, 0.12, 0.02, rng)
+    a = _actions(cloud, 2, 2, 10, rng, spread=0.5)
+    want = O.dynamics(W, 3, cloud, a, task)
+    m.set_precision("bf16x3")
+    out = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(a).to(dev), m, dev, _ppm(task, "granular"))
+    m.set_precision("fp32")
+    err = np.abs(out["state_seqs"].cpu().numpy() - want["state_seqs"]).max()
+    print(f"bf16x3 20-step free-running error vs oracle {err:.2e}")
+    assert err <= POS_TOL
