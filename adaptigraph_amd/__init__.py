@@ -12,7 +12,8 @@ from .model import DynamicsPredictor
 from .plan_utils import decode_action
 from .losses import chamfer, mean_chamfer, box_loss, rope_penalty, cloth_penalty, granular_penalty
 from .costs import running_cost
+from .physics_param_optimizer import dynamics_error
 
 __all__ = ["Engine", "default_engine", "dynamics", "dynamics_masked", "EdgeList", "construct_edges_from_states_batch",
            "construct_edges_index", "pad_torch", "truncate_graph", "DynamicsPredictor", "decode_action", "chamfer",
-           "mean_chamfer", "box_loss", "rope_penalty", "cloth_penalty", "granular_penalty", "running_cost"]
+           "mean_chamfer", "box_loss", "rope_penalty", "cloth_penalty", "granular_penalty", "running_cost", "dynamics_error"]

@@ -100,3 +100,17 @@ def running_cost(state, action, state_cur, error_func, penalty_func, bbox):
                     np.maximum(zmin - F32(bb[1, 0]), 0), np.maximum(F32(bb[1, 1]) - zmax, 0)], -1)   # :45-50
     box = np.exp(-box * F32(100.0)).max(-1)                                             # :51
     return (-error_weight * error[:, -1] - F32(5.0) * pen.mean(1, dtype=F32) - F32(5.0) * box.mean(1, dtype=F32)).astype(F32)
+
+
+def dynamics_error(W, pstep, physics_value, task, state_init_list, state_real_list, actions):
+    """physics_param_optimizer.py:178-226 with the oracle's dynamics_masked and mean_chamfer."""
+    from oracle import adaptigraph_oracle as O
+    n, max_nobj = len(actions), task["max_nobj"]
+    init = np.zeros((n, max_nobj, 3), F32); fin = np.zeros((n, max_nobj, 3), F32)
+    im = np.zeros((n, max_nobj), bool); fm = np.zeros((n, max_nobj), bool)
+    for i in range(n):
+        ni, nf = state_init_list[i].shape[0], state_real_list[i].shape[0]
+        init[i, :ni], fin[i, :nf] = state_init_list[i], state_real_list[i]
+        im[i, :ni], fm[i, :nf] = True, True
+    out = O.dynamics_masked(W, pstep, init, im, np.stack(actions, 0), task, physics_param=physics_value)
+    return float(mean_chamfer(out["state_seqs"], fin, im, fm).mean())

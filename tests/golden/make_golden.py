@@ -427,7 +427,7 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and "--costs" not in sys.argv:
+if __name__ == "__main__" and "--costs" not in sys.argv and "--ppm" not in sys.argv:
     main()
 
 
@@ -494,3 +494,54 @@ def gen_cost_cases(name):
 
 if __name__ == "__main__" and "--costs" in sys.argv:
     gen_cost_cases("costs")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Row (f) rank 4 of SURVEY §8: the inner loop of the physics-parameter optimiser, dynamics_error
+# (src/planning/physics_param_optimizer.py:178-226).  The module imports skopt / cma (absent), so - as for
+# running_cost - that one function is parsed out of the file and compiled against the reference's own
+# dynamics_masked and mean_chamfer.
+def gen_ppm_case(name):
+    import ast
+    import copy
+    refs = import_reference()
+    DynamicsPredictor, _, _, dynamics_masked = refs
+    sys.path.insert(0, REF)
+    from planning.losses import mean_chamfer
+    src = open(f"{REF}/planning/physics_param_optimizer.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "dynamics_error"][0]
+    ns = {"torch": torch, "np": np, "copy": copy, "dynamics_masked": dynamics_masked, "mean_chamfer": mean_chamfer}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), f"{REF}/planning/physics_param_optimizer.py", "exec"), ns)
+    dynamics_error = ns["dynamics_error"]
+    rng = np.random.default_rng(41)
+    dyn, task = load_cfg("rope")
+    task = dict(task)
+    task["max_nR"] = 4000
+    task["max_nobj"] = 110
+    model = make_model(DynamicsPredictor, dyn, 41)
+    ppm = make_ppm(task, "rope")
+    ppm.model = model
+    ppm.device = torch.device("cpu")
+    counts = [110, 70, 93, 101]
+    inits = [rope_cloud(c, rng) for c in counts]
+    reals = [(rope_cloud(c2, rng) + np.float32([0.05, 0.0, 0.03])).astype(np.float32) for c2 in (104, 70, 99, 88)]
+    acts = [actions_near(inits[i], 1, 1, rng, 2.2, 4.8)[0, 0] for i in range(len(counts))]
+    store = weights_npz(model)
+    store["pstep"] = np.int32(dyn["model_config"]["pstep"])
+    store["task_json"] = np.frombuffer(json.dumps({**task_scalars(task), "max_nobj": 110}).encode(), dtype=np.uint8)
+    store["n_act"] = np.int32(len(counts))
+    for i in range(len(counts)):
+        store[f"init{i}"], store[f"real{i}"], store[f"act{i}"] = inits[i], reals[i], acts[i]
+    errs = []
+    for pp in ([0.5], [0.1], np.array([0.83], np.float32)):
+        np.random.seed(0)
+        errs.append(float(quiet(dynamics_error, pp, ppm, inits, reals, acts)))
+    store["phys_values"] = np.array([0.5, 0.1, 0.83], np.float32)
+    store["errors"] = np.array(errs, np.float64)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: errors {errs} -> {os.path.getsize(path)/1e6:.2f} MB")
+
+
+if __name__ == "__main__" and "--ppm" in sys.argv:
+    gen_ppm_case("ppm_dynamics_error")

@@ -321,3 +321,19 @@ def test_bf16x3_twenty_step_free_running(ag, O, dev):
     err = np.abs(out["state_seqs"].cpu().numpy() - want["state_seqs"]).max()
     print(f"bf16x3 20-step free-running error vs oracle {err:.2e}")
     assert err <= POS_TOL
+
+
+def test_ppm_dynamics_error_vs_reference_golden(ag, dev):
+    """the physics-parameter optimiser's objective (physics_param_optimizer.py:178-226)."""
+    from helpers import load_golden, task_of
+    from test_gpu_parity import _model as golden_model
+    g = load_golden("ppm_dynamics_error")
+    task = task_of(g)
+    m = golden_model(ag, g, "rope", dev)
+    ppm = _ppm(task, "rope")
+    ppm.model, ppm.device = m, dev
+    n = int(g["n_act"])
+    inits, reals, acts = ([g[f"{k}{i}"] for i in range(n)] for k in ("init", "real", "act"))
+    for v, want in zip(g["phys_values"], g["errors"]):
+        got = float(ag.dynamics_error([float(v)], ppm, inits, reals, acts))
+        assert abs(got - want) < 2e-5, (v, got, want)

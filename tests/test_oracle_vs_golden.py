@@ -97,3 +97,14 @@ def test_costs_losses_vs_reference():
             r = C.running_cost(g["state"], g["action"], g["state_cur"], err, pen, g["bbox"])
             want = g[f"reward::{err_name}::{kind}"]
             assert np.abs(r - want).max() < 5e-5 * max(1.0, np.abs(want).max()), (err_name, kind)
+
+
+def test_ppm_dynamics_error_vs_reference():
+    from oracle import costs_oracle as C
+    g = load_golden("ppm_dynamics_error")
+    W, task = O.weights_from_npz(g), task_of(g)
+    n = int(g["n_act"])
+    inits, reals, acts = ([g[f"{k}{i}"] for i in range(n)] for k in ("init", "real", "act"))
+    for v, want in zip(g["phys_values"], g["errors"]):
+        got = C.dynamics_error(W, int(g["pstep"]), float(v), task, inits, reals, acts)
+        assert abs(got - want) < 2e-5, (v, got, want)
