@@ -207,6 +207,26 @@ def main():
             dist.all_reduce(tb3, op=dist.ReduceOp.MAX)
         dt_b3 = float(tb3.item())
         assert torch.isfinite(costs_b3).all()
+    # ---- ms / MPC iteration (BASELINE metric, second half): sample -> rollout -> running_cost -> MPPI update -> best
+    # candidate rolled out again (planner.py:234-277), whole batch in one call, exact fp32
+    lo_lim = torch.tensor([float(cloud[:, 0].min()) - 0.5, float(cloud[:, 2].min()) - 0.5, -3.14, R + 0.5], device=dev)
+    hi_lim = torch.tensor([float(cloud[:, 0].max()) + 0.5, float(cloud[:, 2].max()) + 0.5, 3.14, R + 0.5], device=dev)
+    roll_fn = lambda s, a: ag.dynamics(s, a, model, dev, ppm, _sync=False, _overflow_flag=flag)
+    eval_fn = partial(ag.running_cost, error_func=err_fn, penalty_func=pen_fn, bbox=bbox, group=True if world > 1 else None)
+    act0 = actions[0].to(dev)
+    torch.manual_seed(1234)                                        # identical samples on every rank
+    ag.mpc_iteration(state0, act0, roll_fn, eval_fn, lo_lim, hi_lim, B, dev, group=True if world > 1 else None)
+    sync_all()
+    t0 = time.perf_counter()
+    n_mpc = 2
+    for _ in range(n_mpc):
+        mpc = ag.mpc_iteration(state0, act0, roll_fn, eval_fn, lo_lim, hi_lim, B, dev, group=True if world > 1 else None)
+    sync_all()
+    tm = torch.tensor([(time.perf_counter() - t0) / n_mpc], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    ms_mpc = float(tm.item()) * 1e3
+    assert torch.isfinite(mpc["reward_seqs"]).all()
     ms_edge, n_edge = eng.kernel_stats("edge_enc") if fams else (0.0, 0)
     fam_ms = {f: eng.kernel_stats(f) for f in fams}
     if rank == 0:
@@ -240,7 +260,7 @@ def main():
                                    "repeat 10) x 2025+1 particles, radius graph rebuilt every step",
                        "candidates": B, "horizon": H * R, "particles": N_o + 1, "edges_per_graph": E, "edges_encoded_per_graph": E_enc,
                        "parallelism": f"candidates sharded over {world} GPU(s), all-gather of costs",
-                       "ms_per_mpc_rollout": dt / args.steps * 1e3},
+                       "ms_per_mpc_rollout": dt / args.steps * 1e3, "ms_per_mpc_iter": ms_mpc},
             "roofline": {"bound": "mfma", "kernel": "k_edge_enc", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": int(n_edge),

@@ -427,7 +427,7 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and "--costs" not in sys.argv and "--ppm" not in sys.argv:
+if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi"} & set(sys.argv)):
     main()
 
 
@@ -545,3 +545,36 @@ def gen_ppm_case(name):
 
 if __name__ == "__main__" and "--ppm" in sys.argv:
     gen_ppm_case("ppm_dynamics_error")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Row (f) rank 2 of SURVEY §8: MPPI sampling / update (src/planning/plan_utils.py:31-101), CPU torch, seeded.
+def gen_mppi_case(name):
+    import_reference()
+    sys.path.insert(0, REF)
+    from planning import plan_utils as PU
+    lo = torch.tensor([-4.5, -2.5, -3.14, 2.0])
+    hi = torch.tensor([0.0, 4.5, 3.14, 10.0])
+    store = {"lo": lo.numpy(), "hi": hi.numpy()}
+    torch.manual_seed(123)
+    act_seq = torch.rand(3, 4) * (hi - lo) + lo
+    store["act_seq"] = act_seq.numpy()
+    torch.manual_seed(7)
+    s0 = PU.sample_action_seq(act_seq, lo, hi, 64, torch.device("cpu"), iter_index=0, noise_level=1.0, push_length=0.1)
+    torch.manual_seed(8)
+    s1 = PU.sample_action_seq(act_seq, lo, hi, 64, torch.device("cpu"), iter_index=1, noise_level=0.3, push_length=0.1)
+    store["sample_iter0"], store["sample_iter1"] = s0.numpy(), s1.numpy()
+    torch.manual_seed(9)
+    rewards = torch.randn(64) * 0.02 - 5.0
+    store["rewards"] = rewards.numpy()
+    store["mppi"] = PU.optimize_action_mppi(s1, rewards, reward_weight=500.0, action_lower_lim=lo, action_upper_lim=hi,
+                                            push_length=0.1).numpy()
+    wild = torch.randn(5, 3, 4) * 6.0
+    store["wild"] = wild.numpy()
+    store["clipped"] = PU.clip_actions(wild, lo, hi).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+    print(f"{name}: mppi update {store['mppi'][0]}")
+
+
+if __name__ == "__main__" and "--mppi" in sys.argv:
+    gen_mppi_case("mppi")
