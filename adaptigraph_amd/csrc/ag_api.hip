@@ -478,6 +478,35 @@ int ag_build_edges(ag_ctx* c, void* stream, const float* d_pos, const uint8_t* d
     return AG_OK;
 }
 
+int ag_build_edges_single(ag_ctx* c, void* stream, const float* d_pos, const uint8_t* d_mask, const uint8_t* d_tool,
+                          int32_t N, float thr2, float cull_radius, int32_t topk, int32_t cta, int32_t edge_cap,
+                          int32_t* d_recv, int32_t* d_send, int32_t* d_row_ptr, int32_t* d_n_edges) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_pos || !d_mask || !d_tool || !d_recv || !d_send || !d_row_ptr || !d_n_edges || edge_cap < 1)
+        return fail(c, AG_ERR_INVALID, "ag_build_edges_single: null pointer");
+    if (!(cull_radius * cull_radius >= thr2)) return fail(c, AG_ERR_INVALID, "cull_radius^2 must be >= thr2");
+    int rc = check_topk(c, N, topk);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int slices = pick_slices(1, N);
+    const int ell_stride = edge_ell_stride(N, topk);
+    rc = ensure_slab(c, (size_t)N * (size_t)(ell_stride + 1) * 4 + (size_t)(slices + 1) * 4 + 4096);
+    if (rc) return rc;
+    EdgeArgs a{};
+    a.pos = d_pos; a.pos_bstride = (long)N * 3; a.mask = d_mask; a.tool = d_tool; a.thr_vec = nullptr; a.thr = cull_radius;
+    a.thr2_override = thr2; a.use_thr2 = 1;
+    a.B = 1; a.N = N; a.topk = topk; a.cta = cta ? 2 : 0; a.edge_cap = edge_cap; a.slices = slices;
+    a.ell = c->slab.take<int>((size_t)N * (size_t)std::max(1, ell_stride));
+    a.deg = c->slab.take<int>(N);
+    a.slice_tot = c->slab.take<int>(slices);
+    a.cta_flag = c->slab.take<int>(1);
+    a.recv = d_recv; a.send = d_send; a.row_ptr = d_row_ptr; a.n_edges = d_n_edges; a.overflow = nullptr;
+    a.max_nR = edge_cap; a.zero_on_overflow = 0;
+    c->prof_stream = static_cast<hipStream_t>(stream);
+    HIPCHK(c, launch_edge_build(a, static_cast<hipStream_t>(stream), prof_mark, c));
+    return AG_OK;
+}
+
 int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_attrs, const float* d_action,
                const float* d_phys, const float* d_group, int32_t n_inst, const int32_t* d_recv, const int32_t* d_send,
                const int32_t* d_row_ptr, const int32_t* d_n_edges, int32_t edge_cap, int32_t B, int32_t N, int32_t n_p,

@@ -66,8 +66,9 @@ struct EdgeArgs {
     const uint8_t* mask;        // (B,N)
     const uint8_t* tool;        // (B,N)
     const float* thr_vec;       // (B,) or null
-    float thr;
-    int B, N, topk, cta, edge_cap, slices;
+    float thr;                  // also the chunk-culling radius: must satisfy thr*thr >= the squared threshold in use
+    float thr2_override; int use_thr2;   // single-graph builder (graph.py:86,101)
+    int B, N, topk, cta, edge_cap, slices;   // cta: 0 off, 1 batch rule (graph.py:276-286), 2 single-graph rule (:119-122)
     int* ell;                   // (B,N,min(topk,N)) scratch: kept senders per row (unused when topk >= N)
     int* deg;                   // (B,N) scratch
     int* slice_tot;             // (B,slices) scratch

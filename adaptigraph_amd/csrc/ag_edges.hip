@@ -44,6 +44,7 @@ constexpr unsigned long long KEY_INF = ~0ull;
 struct EdgeDev {
     const float* pos; long pos_bstride;  // floats between candidates
     const uint8_t* mask; const uint8_t* tool; const float* thr_vec; float thr;
+    float thr2_override; int use_thr2;   // single-graph builder: threshold squared in double, then rounded (graph.py:86,101)
     int B, N, k, topk_active, cta, edge_cap, slices, rows_per_slice;
     int* ell;                            // (B, N, k) kept non-merged senders per row (top-k active only)
     int* deg; int* slice_tot; int* cta_flag;
@@ -307,11 +308,14 @@ __device__ __forceinline__ bool member_radius(const EdgeDev& a, const EdgeLds& l
     const bool within = (fi & 1) && pair_within(l, a.N, xi, yi, zi, fi, j, thr2, d, fj);
     if (!a.cta) return within;
     if (j >= a.N) return false;
-    if (fj & 2) return (fi & 1) && flag;                   // graph.py:284,286
-    return within && !(fi & 2);                            // graph.py:283,285
+    if (fj & 2) return (fi & 1) && flag && !(a.cta == 2 && (fi & 2));   // graph.py:284,286 | single-graph: :121-122
+    return within && !(fi & 2);                            // graph.py:283,285 | :120
 }
 
 __device__ __forceinline__ float thr_of(const EdgeDev& a, int b) { return a.thr_vec ? a.thr_vec[b] : a.thr; }
+// squared threshold of the adjacency test: fp32*fp32 for the batch builder (graph.py:250), a caller-supplied value
+// for the single-graph builder, whose Python squares in double before the fp32 subtraction (graph.py:86,101)
+__device__ __forceinline__ float thr2_of(const EdgeDev& a, float thr) { return a.use_thr2 ? a.thr2_override : __fmul_rn(thr, thr); }
 
 // number of final senders of row i when top-k is not active (full sweep with culling); nontool_raw as above
 __device__ int row_radius_count(const EdgeDev& a, const EdgeLds& l, int i, float thr, float thr2, int flag, int* nontool_raw) {
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(EW) void k_edge_count(EdgeDev a) {
     const EdgeLds l = carve(smem, a.N);
     load_candidate(a, l, b, true);
     const float thr = thr_of(a, b);
-    const float thr2 = __fmul_rn(thr, thr);                // graph.py:250 fp32 * fp32
+    const float thr2 = thr2_of(a, thr);
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int r0 = sl * a.rows_per_slice;
     const int r1 = min(a.N, r0 + a.rows_per_slice);
@@ -349,22 +353,23 @@ __global__ __launch_bounds__(EW) void k_edge_count(EdgeDev a) {
     for (int i = wave; i < a.N; i += EWAVES) {
         const bool mine = i >= r0 && i < r1;
         const bool is_tool = l.fl[i] & 2;
-        if (!mine && !(a.cta && is_tool)) continue;        // wave-uniform
+        if (!mine && !(a.cta == 1 && is_tool)) continue;   // wave-uniform
         int raw = 0, n;
         if (a.topk_active) n = row_topk(a, l, i, thr, thr2, a.ell + ((long)b * a.N + i) * a.k, &raw);
         else n = row_radius_count(a, l, i, thr, thr2, 0, &raw);
         if (lane == 0) {
             if (mine) a.deg[(long)b * a.N + i] = n;        // senders not governed by the tool rule
-            if (a.cta && is_tool && raw) atomicOr(&l.misc[0], 1);
+            if (a.cta == 1 && is_tool && raw) atomicOr(&l.misc[0], 1);
         }
     }
     __syncthreads();
-    const int flag = l.misc[0];
+    // batch builder: all-or-nothing flag (graph.py:277); single-graph builder (cta == 2): unconditional (graph.py:119-122)
+    const int flag = a.cta == 2 ? 1 : l.misc[0];
     // pass 2: add the all-or-nothing tool senders (graph.py:284,286) and total the slice
     int my = 0;
     for (int i = r0 + threadIdx.x; i < r1; i += EW) {
         int d = a.deg[(long)b * a.N + i];
-        if (a.cta && (l.fl[i] & 1) && flag) d += ntool;
+        if (a.cta && (l.fl[i] & 1) && flag && !(a.cta == 2 && (l.fl[i] & 2))) d += ntool;
         a.deg[(long)b * a.N + i] = d;
         my += d;
     }
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
         for (int i = r0 + wave; i < r1; i += EWAVES) {
             const int off = a.row_ptr[(long)b * (a.N + 1) + i];
             const int d = a.deg[(long)b * a.N + i];
-            const bool row_tools = tools_on && (l.fl[i] & 1);
+            const bool row_tools = tools_on && (l.fl[i] & 1) && !(a.cta == 2 && (l.fl[i] & 2));
             const int nt = row_tools ? ntool : 0;
             const int nk = d - nt;                          // kept senders from the ELL row
             const int* ell = a.ell + ((long)b * a.N + i) * a.k;
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
         }
     } else {
         const float thr = thr_of(a, b);
-        const float thr2 = __fmul_rn(thr, thr);
+        const float thr2 = thr2_of(a, thr);
         for (int i = r0 + wave; i < r1; i += EWAVES) {
             const float xi = l.x[i], yi = l.y[i], zi = l.z[i];
             const int fi = l.fl[i];
@@ -498,6 +503,7 @@ __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
 hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(void*, int, int), void* mark_ctx) {
     EdgeDev a;
     a.pos = h.pos; a.pos_bstride = h.pos_bstride; a.mask = h.mask; a.tool = h.tool; a.thr_vec = h.thr_vec; a.thr = h.thr;
+    a.thr2_override = h.thr2_override; a.use_thr2 = h.use_thr2;
     a.B = h.B; a.N = h.N; a.k = min(h.N, h.topk); a.topk_active = a.k < h.N; a.cta = h.cta; a.edge_cap = h.edge_cap;
     a.slices = h.slices; a.rows_per_slice = (h.N + h.slices - 1) / h.slices;
     a.ell = h.ell; a.deg = h.deg; a.slice_tot = h.slice_tot; a.cta_flag = h.cta_flag;

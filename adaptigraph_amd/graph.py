@@ -110,6 +110,42 @@ def construct_edges_from_states_batch(states, adj_thresh, mask, tool_mask, topk=
     return el.to_dense()
 
 
+def construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=10, connect_tools_all=False, max_y=None,
+                                min_y=None, max_x=None, max_z=None, min_x=None, min_z=None, connect_tools_surface=False,
+                                connect_tool_all_non_fixed=True, kNN=1.0, as_index=False):
+    """Drop-in for the single-graph builder (graph.py:68-231), default-argument path: states (N,3), mask/tool_mask (N,)
+    -> dense one-hot (Rr, Rs) of shape (n_rel, N) (or an EdgeList with as_index=True).  The tool-surface / kNN /
+    non-fixed-particle branches (graph.py:125-221) need max_y etc.; they are not implemented."""
+    if (connect_tool_all_non_fixed and max_y is not None and min_y is not None) or \
+            (connect_tools_surface and None not in (max_y, max_x, min_x, max_z, min_z)):
+        raise NotImplementedError("tool-surface / non-fixed-particle edge rules (graph.py:125-221) are not implemented")
+    import numpy as np
+    dev = _require_gpu(states.device)
+    eng = default_engine(dev)
+    pos = states.to(torch.float32).contiguous()
+    N = pos.shape[0]
+    thr = float(adj_thresh)
+    thr2 = float(np.float32(thr * thr))                                     # double product, one fp32 rounding (:86,101)
+    cull = float(np.nextafter(np.float32(abs(thr)), np.float32(np.inf)))    # cull^2 >= thr2 whatever the rounding did
+    mask_u8 = mask.to(dev).to(torch.bool).contiguous().view(torch.uint8)
+    tool_u8 = tool_mask.to(dev).to(torch.bool).contiguous().view(torch.uint8)
+    k = min(N, int(topk))
+    m = int(tool_mask.to(torch.bool).sum().item())
+    edge_cap = max(1, N * (k + m) if k < N else N * N)
+    recv = torch.empty((1, edge_cap), device=dev, dtype=torch.int32)
+    send = torch.empty((1, edge_cap), device=dev, dtype=torch.int32)
+    row_ptr = torch.empty((1, N + 1), device=dev, dtype=torch.int32)
+    n_edges = torch.empty((1,), device=dev, dtype=torch.int32)
+    eng.check(eng.lib.ag_build_edges_single(eng.ctx, current_stream(dev), ptr(pos), ptr(mask_u8), ptr(tool_u8), N, thr2,
+                                            cull, int(topk), int(bool(connect_tools_all)), edge_cap, ptr(recv), ptr(send),
+                                            ptr(row_ptr), ptr(n_edges)))
+    el = EdgeList(recv, send, row_ptr, n_edges, N)
+    if as_index:
+        return el
+    Rr, Rs = el.to_dense()
+    return Rr[0], Rs[0]
+
+
 def pad_torch(x, max_dim, dim=0):
     """src/dynamics/utils.py:49-69: zero-pad `dim` to max_dim, raise Exception('Exceeds max dims') when larger."""
     if dim == 0:

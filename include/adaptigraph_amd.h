@@ -110,6 +110,16 @@ int ag_build_edges(ag_ctx* ctx, void* stream, const float* d_pos, const uint8_t*
                    int32_t connect_tools_all, int32_t edge_cap, int32_t* d_recv, int32_t* d_send,
                    int32_t* d_row_ptr, int32_t* d_n_edges);
 
+/* Replaces the default-argument path of construct_edges_from_states (src/dynamics/dataset/graph.py:68-231, single
+ * graph; the dataset / eval-rollout builder).  Differences from the batch builder that are reproduced: the squared
+ * threshold is formed in double precision and then rounded (h: thr2 = (float)((double)adj*adj), graph.py:86,101 - one ulp
+ * away from the batch builder's fp32 square for e.g. 0.4); connect_tools_all is unconditional and leaves no
+ * tool<->tool edge (graph.py:119-122).  cull_radius: any float with cull_radius^2 >= thr2 (e.g. nextafter(adj)).
+ * The tool-surface / kNN / non-fixed-particle options of that function (max_y, kNN, ...) are not implemented. */
+int ag_build_edges_single(ag_ctx* ctx, void* stream, const float* d_pos, const uint8_t* d_mask, const uint8_t* d_tool_mask,
+                          int32_t N, float thr2, float cull_radius, int32_t topk, int32_t connect_tools_all,
+                          int32_t edge_cap, int32_t* d_recv, int32_t* d_send, int32_t* d_row_ptr, int32_t* d_n_edges);
+
 /* Replaces DynamicsPredictor.forward (src/dynamics/gnn/model.py:130-342) on index-list graphs.
  *   d_state (B,n_his,N,3); d_attrs (B,N,2); d_action (B,N,3); d_phys (B,N) physics parameter per particle, zero
  *   for the trailing N-n_p tool particles (model.py:206-207); d_group (B,N,n_inst) = [p_instance ; 0] (model.py:264);

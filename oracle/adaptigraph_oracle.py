@@ -94,6 +94,35 @@ def construct_edges_single(pos, thr, mask, tool_mask, topk, connect_tools_all, c
     return recv.astype(np.int32), send.astype(np.int32)
 
 
+def construct_edges_from_states(pos, adj_thresh, mask, tool_mask, topk=10, connect_tools_all=False, check_ties=False):
+    """Default-argument path of the SINGLE-graph builder (graph.py:68-231; max_y etc. None, so :125-221 are inactive).
+    Differs from the batch builder in two reproduced ways: the threshold is squared in Python double precision and only
+    then meets the fp32 distances (:86,101), and connect_tools_all is unconditional with tool<->tool removed (:119-122)."""
+    N = pos.shape[0]
+    thr2 = F32(float(adj_thresh) * float(adj_thresh))               # :86 double product, rounded by the fp32 subtraction
+    dis = pairwise_dis(pos)                                         # :87-88
+    mask = np.asarray(mask, bool)
+    tool = np.asarray(tool_mask, bool)
+    dis[~(mask[:, None] & mask[None, :])] = BIG                     # :89-92
+    t12 = tool[:, None] & tool[None, :]
+    dis[t12] = BIG                                                  # :93-96
+    adj = (dis - thr2) < 0                                          # :101
+    k = min(N, int(topk))                                           # :109
+    if k < N:
+        kth = np.partition(dis, k - 1, axis=1)[:, k - 1][:, None]
+        less, eq = dis < kth, dis == kth
+        need = k - less.sum(1, keepdims=True)
+        if check_ties and ((eq.sum(1, keepdims=True) > need) & (kth < thr2)).any():
+            raise TopkTie("tie at the k-th boundary inside the radius")
+        adj &= less | (eq & (np.cumsum(eq, axis=1) <= need))
+    if connect_tools_all:                                           # :119-122
+        adj[tool[:, None] & mask[None, :]] = False
+        adj[tool[None, :] & mask[:, None]] = True
+        adj[t12] = False
+    recv, send = np.nonzero(adj)                                    # :225
+    return recv.astype(np.int32), send.astype(np.int32)
+
+
 def construct_edges_batch(states, adj_thresh, mask, tool_mask, topk=10, connect_tools_all=False, check_ties=False):
     """graph.py:233-298 for a batch.  adj_thresh: python float or (B,) array.  Returns list of (recv, send)."""
     states = np.asarray(states, F32)

@@ -427,7 +427,7 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single"} & set(sys.argv)):
     main()
 
 
@@ -578,3 +578,52 @@ def gen_mppi_case(name):
 
 if __name__ == "__main__" and "--mppi" in sys.argv:
     gen_mppi_case("mppi")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Row (f) rank 3 of SURVEY §8: the single-graph builder construct_edges_from_states (graph.py:68-231), default path.
+def gen_single_edges(name):
+    import_reference()
+    from dynamics.dataset.graph import construct_edges_from_states
+    rng = np.random.default_rng(77)
+    store, cases = {}, []
+    for ci, (N_o, M, topk, thr, cta) in enumerate([(120, 1, 10, 0.5, False), (150, 5, 20, 0.4, False),
+                                                    (150, 5, 20, 0.4, True), (100, 1, 5, 0.75, True), (40, 2, 100, 0.45, True)]):
+        N = N_o + M
+        side = int(np.ceil(np.sqrt(N_o)))
+        pitch = 0.12 if thr < 0.45 else 0.3 if thr > 0.7 else 0.1
+        states = np.zeros((N, 3), np.float32)
+        states[:N_o] = grid_cloud(side, pitch, 0.02, rng)[:N_o]
+        mask = np.ones(N, bool)
+        mask[N_o - 9:N_o - 3] = False                                          # a hole of invalid particles
+        tool = np.zeros(N, bool)
+        tool[N_o:] = True
+        for m in range(M):
+            states[N_o + m] = states[N_o // 2] + np.float32([0.05 * m + 0.01, 0.0, 0.04 * m + 0.02])
+        ts = torch.from_numpy(states)
+        assert_no_topk_boundary_tie(ts[None], torch.from_numpy(mask)[None], torch.from_numpy(tool)[None], thr, topk)
+        Rr, Rs = quiet(construct_edges_from_states, ts, thr, torch.from_numpy(mask), torch.from_numpy(tool),
+                       topk=topk, connect_tools_all=cta)
+        pre = f"case{ci}::"
+        store[pre + "states"], store[pre + "mask"], store[pre + "tool_mask"] = states, mask, tool
+        pack_edges(pre, edges_from_R(Rr[None], Rs[None]), store)
+        cases.append({"topk": topk, "adj_thresh": thr, "connect_tools_all": cta})
+    # the 1-ulp case of SURVEY a5'(ii): a pair at dis == fp32(0.16) exactly, adj_thresh 0.4
+    # a pair whose fp32 distance is EXACTLY fp32(0.16): found by search, dx^2 + dz^2 with dx = 0.30000001192092896
+    states = np.array([[0.0, 0.0, 0.0], [0.30000001192092896, 0.0, 0.26457512378692627], [5.0, 0.0, 0.0]], np.float32)
+    d = np.float32(np.float32(states[1, 0] * states[1, 0]) + np.float32(states[1, 2] * states[1, 2]))
+    assert d == np.float32(0.16)
+    store["ulp::dis"] = np.float32(d)
+    mask, tool = np.ones(3, bool), np.zeros(3, bool)
+    Rr, Rs = quiet(construct_edges_from_states, torch.from_numpy(states), 0.4, torch.from_numpy(mask), torch.from_numpy(tool), topk=3)
+    pre = f"case{len(cases)}::"
+    store[pre + "states"], store[pre + "mask"], store[pre + "tool_mask"] = states, mask, tool
+    pack_edges(pre, edges_from_R(Rr[None], Rs[None]), store)
+    cases.append({"topk": 3, "adj_thresh": 0.4, "connect_tools_all": False})
+    store["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+    print(f"{name}: {len(cases)} cases, last-case edges {len(store[pre + 'recv'])}, dis {d!r}")
+
+
+if __name__ == "__main__" and "--single" in sys.argv:
+    gen_single_edges("edges_single")

@@ -370,3 +370,28 @@ def test_mpc_iteration_end_to_end(ag, O, dev):
     best = out["act_seq"].cpu().numpy()[None]
     want = O.dynamics(W, 3, cloud, best, task)["state_seqs"]
     assert np.abs(out["best_model_output"]["state_seqs"].cpu().numpy() - want).max() <= POS_TOL
+
+
+def test_single_graph_builder_vs_reference_golden(ag, dev):
+    """construct_edges_from_states (default path), incl. the double-precision threshold quirk."""
+    import json
+    from helpers import load_golden, split_edges
+    g = load_golden("edges_single")
+    cases = json.loads(bytes(g["cases_json"]).decode())
+    for ci, c in enumerate(cases):
+        pre = f"case{ci}::"
+        args = (torch.from_numpy(g[pre + "states"]).to(dev), c["adj_thresh"], torch.from_numpy(g[pre + "mask"]).to(dev),
+                torch.from_numpy(g[pre + "tool_mask"]).to(dev))
+        el = ag.construct_edges_from_states(*args, topk=c["topk"], connect_tools_all=c["connect_tools_all"], as_index=True)
+        (r, s), = _edges_to_lists(el)
+        (wr, ws), = split_edges(g, pre)
+        assert np.array_equal(r, wr) and np.array_equal(s, ws), ci
+        Rr, Rs = ag.construct_edges_from_states(*args, topk=c["topk"], connect_tools_all=c["connect_tools_all"])
+        assert Rr.shape == (len(wr), g[pre + "states"].shape[0]) and np.array_equal(Rr.argmax(-1).cpu().numpy(), wr)
+    with pytest.raises(NotImplementedError):
+        ag.construct_edges_from_states(*args, max_y=1.0, min_y=0.0)
+    # last case: a pair at distance^2 == fp32(0.16) exactly, adj_thresh 0.4.  The single-graph builder (double-precision
+    # square) leaves it unconnected; the batch builder (fp32 square = 0.16000001) connects it (SURVEY a5'(ii)).
+    assert len(wr) == 3
+    elb = ag.construct_edges_index(args[0][None], 0.4, args[2][None], args[3][None], 3, False)
+    assert int(elb.n_edges[0]) == 5

@@ -108,3 +108,15 @@ def test_ppm_dynamics_error_vs_reference():
     for v, want in zip(g["phys_values"], g["errors"]):
         got = C.dynamics_error(W, int(g["pstep"]), float(v), task, inits, reals, acts)
         assert abs(got - want) < 2e-5, (v, got, want)
+
+
+def test_single_graph_builder_vs_reference():
+    import json
+    g = load_golden("edges_single")
+    cases = json.loads(bytes(g["cases_json"]).decode())
+    for ci, c in enumerate(cases):
+        pre = f"case{ci}::"
+        r, s = O.construct_edges_from_states(g[pre + "states"], c["adj_thresh"], g[pre + "mask"], g[pre + "tool_mask"],
+                                             c["topk"], c["connect_tools_all"])
+        (wr, ws), = split_edges(g, pre)
+        assert np.array_equal(r, wr) and np.array_equal(s, ws), ci
