@@ -76,27 +76,50 @@ __global__ __launch_bounds__(CT) void k_chamfer(ChamferDev a) {
     }
     __syncthreads();
     float sum_y = 0.f, cnt_y = 0.f, sum_x = 0.f, cnt_x = 0.f;
-    for (int j = tid; j < a.M; j += CT) {                  // for every y point the nearest x
-        const float yx = ys[j], yy = ys[a.M + j], yz = ys[2 * a.M + j];
-        if (yx >= BIG) continue;
-        float m = BIG;
+    // register tiling: a lane owns PT points of one cloud, so every LDS broadcast of a point of the other cloud feeds
+    // PT distance evaluations (the sweep is LDS-issue bound otherwise)
+    constexpr int PT = 4;
+    for (int j0 = tid * PT; j0 < a.M; j0 += CT * PT) {     // for every y point the nearest x
+        float yx[PT], yy[PT], yz[PT], m[PT];
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const int j = min(j0 + k, a.M - 1);
+            yx[k] = ys[j]; yy[k] = ys[a.M + j]; yz[k] = ys[2 * a.M + j]; m[k] = BIG;
+        }
         for (int i = 0; i < a.N; ++i) {
-            const float dx = xs[i] - yx, dy = xs[a.N + i] - yy, dz = xs[2 * a.N + i] - yz;
-            const float d = xs[i] >= BIG ? BIG : (dx * dx + dy * dy) + dz * dz;
-            m = fminf(m, d);
+            const float px = xs[i], py = xs[a.N + i], pz = xs[2 * a.N + i];
+            const bool dead = px >= BIG;
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                const float dx = px - yx[k], dy = py - yy[k], dz = pz - yz[k];
+                const float d = dead ? BIG : (dx * dx + dy * dy) + dz * dz;
+                m[k] = fminf(m[k], d);
+            }
         }
-        sum_y += sqrtf(m); cnt_y += 1.f;
+#pragma unroll
+        for (int k = 0; k < PT; ++k)
+            if (j0 + k < a.M && yx[k] < BIG) { sum_y += sqrtf(m[k]); cnt_y += 1.f; }
     }
-    for (int i = tid; i < a.N; i += CT) {                  // for every x point the nearest y
-        const float xx = xs[i], xy = xs[a.N + i], xz = xs[2 * a.N + i];
-        if (xx >= BIG) continue;
-        float m = BIG;
-        for (int j = 0; j < a.M; ++j) {
-            const float dx = xx - ys[j], dy = xy - ys[a.M + j], dz = xz - ys[2 * a.M + j];
-            const float d = ys[j] >= BIG ? BIG : (dx * dx + dy * dy) + dz * dz;
-            m = fminf(m, d);
+    for (int i0 = tid * PT; i0 < a.N; i0 += CT * PT) {     // for every x point the nearest y
+        float xx[PT], xy[PT], xz[PT], m[PT];
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const int i = min(i0 + k, a.N - 1);
+            xx[k] = xs[i]; xy[k] = xs[a.N + i]; xz[k] = xs[2 * a.N + i]; m[k] = BIG;
         }
-        sum_x += sqrtf(m); cnt_x += 1.f;
+        for (int j = 0; j < a.M; ++j) {
+            const float px = ys[j], py = ys[a.M + j], pz = ys[2 * a.M + j];
+            const bool dead = px >= BIG;
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                const float dx = xx[k] - px, dy = xy[k] - py, dz = xz[k] - pz;
+                const float d = dead ? BIG : (dx * dx + dy * dy) + dz * dz;
+                m[k] = fminf(m[k], d);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PT; ++k)
+            if (i0 + k < a.N && xx[k] < BIG) { sum_x += sqrtf(m[k]); cnt_x += 1.f; }
     }
     const float sy = block_sum(sum_y, red), cy = block_sum(cnt_y, red);
     const float sx = block_sum(sum_x, red), cx = block_sum(cnt_x, red);

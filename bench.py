@@ -34,6 +34,24 @@ FLOP_PER_NODE_FINAL = 2 * 150 * 150 + 2 * (2 * 150 * 150 + 3 * 150)             
 PEAK_FP32_MFMA_TFLOPS = 157.3                                                      # MI355X_MICROARCH.md chip table
 
 
+def random_weights(seed, nf=150, in_dim=6, rel_dim=17):
+    """nn.Linear-style U(-1/sqrt(fan_in), 1/sqrt(fan_in)) init of the 22 state_dict tensors (no checkpoint exists
+    offline: SURVEY §4).  Local on purpose: the timed path must not touch oracle/."""
+    rng = np.random.default_rng(seed)
+    shapes = {"particle_encoder.model.0": (nf, in_dim), "particle_encoder.model.2": (nf, nf),
+              "particle_encoder.model.4": (nf, nf), "relation_encoder.model.0": (nf, rel_dim),
+              "relation_encoder.model.2": (nf, nf), "relation_encoder.model.4": (nf, nf),
+              "particle_propagator.linear": (nf, 2 * nf), "relation_propagator.linear": (nf, 3 * nf),
+              "non_rigid_predictor.linear_0": (nf, nf), "non_rigid_predictor.linear_1": (nf, nf),
+              "non_rigid_predictor.linear_2": (3, nf)}
+    W = {}
+    for k, (o, i) in shapes.items():
+        bound = 1.0 / np.sqrt(i)
+        W[k + ".weight"] = rng.uniform(-bound, bound, (o, i)).astype(np.float32)
+        W[k + ".bias"] = rng.uniform(-bound, bound, (o,)).astype(np.float32)
+    return W
+
+
 def cloth_cloud(side, rng):
     g = (np.arange(side) - (side - 1) / 2.0) * 0.3
     xx, zz = np.meshgrid(g, g, indexing="ij")
@@ -115,14 +133,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import adaptigraph_amd as ag
-    from oracle import adaptigraph_oracle as O   # weights generator + cpu_baseline only; never on the timed path
 
     rng = np.random.default_rng(0)
     cloud = cloth_cloud(args.side, rng)
     N_o = cloud.shape[0]
     B, H, R = args.candidates, args.lookahead, args.repeat
     task = make_task(max_nR=int(1.2 * 6 * (N_o + 1)) + 64)
-    Wt = O.random_weights(0)
+    Wt = random_weights(0)
     model = ag.DynamicsPredictor(*model_cfg(), dev)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in Wt.items()})
     ppm = types.SimpleNamespace(task_config=task, eef_num=1, material="cloth", material_dims=task["material_dims"],
