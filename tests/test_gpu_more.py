@@ -395,3 +395,29 @@ def test_single_graph_builder_vs_reference_golden(ag, dev):
     assert len(wr) == 3
     elb = ag.construct_edges_index(args[0][None], 0.4, args[2][None], args[3][None], 3, False)
     assert int(elb.n_edges[0]) == 5
+
+
+@pytest.mark.parametrize("material,n_max,cloud_fn", [
+    ("rope", 150, lambda n, r: _rope(n, r)),
+    ("granular", 160, lambda n, r: _grid(13, 0.12, 0.02, r)[:n]),
+    ("cloth", 169, lambda n, r: _grid(13, 0.3, 0.02, r)[:n]),
+])
+def test_mixed_variable_size_graphs_masked(ag, O, dev, material, n_max, cloud_fn):
+    """BASELINE configs[4] in miniature: variable-size graphs (prefix masks of different lengths) of every material
+    through dynamics_masked - 5-point pusher (granular) and connect_tools_all + gripper (cloth) in masked mode."""
+    rng = np.random.default_rng(50 + n_max)
+    task = _task(material, max_nR=20000)
+    W, m = _model(ag, O, material, 50 + n_max, dev)
+    counts = [n_max, n_max // 2, (3 * n_max) // 4, n_max - 1]
+    B = len(counts)
+    state = np.zeros((B, n_max, 3), np.float32)
+    mask = np.zeros((B, n_max), bool)
+    for b, c in enumerate(counts):
+        state[b, :c] = cloud_fn(c, rng)
+        mask[b, :c] = True
+    a = _actions(state[0], B, 1, [2, 3, 1, 4], rng, spread=0.4)[:, 0]
+    out = ag.dynamics_masked(torch.from_numpy(state).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(a).to(dev),
+                             m, dev, _ppm(task, material))
+    want = O.dynamics_masked(W, 3, state, mask, a, task)
+    err = np.abs(out["state_seqs"].cpu().numpy() - want["state_seqs"]).max()
+    assert err <= POS_TOL, err
