@@ -22,6 +22,7 @@
 //   * Rows are independent columns of the MFMA, so results do not depend on which lane / workgroup / chunk / GPU a
 //     row lands in: sharded == unsharded bit-for-bit.
 #include "ag_common.h"
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 
@@ -189,6 +190,9 @@ __device__ __forceinline__ void store_rows(const Act& a, float* __restrict__ bas
             v[0] = a.t[t][4 * q + 0]; v[1] = a.t[t][4 * q + 1]; v[2] = a.t[t][4 * q + 2]; v[3] = a.t[t][4 * q + 3];
             *reinterpret_cast<f32x4*>(p + 32 * t + 8 * q) = v;
         }
+    // keep the next layer's accumulator writes behind these stores (else the 80 source registers stay live under a
+    // renamed accumulator and the kernel spills)
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // One full 160-wide layer, weights streamed in four K-quarters through two LDS buffers.
@@ -468,52 +472,107 @@ template <int NK, int MB>
 __device__ __forceinline__ void mma_b3(const float* wl, const bf16x8* bh, const bf16x8* bm, const bf16x8* bl,
                                        f32x16* acc, int lane) {
     const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+    // weight pieces double-buffered one m-block ahead and pinned there: left alone the scheduler hoists the reads
+    // of several m-blocks (12 VGPRs each) over the live accumulators and spills
+    bf16x8 ah = w[0 * 64 + lane], am = w[1 * 64 + lane], al = w[2 * 64 + lane];
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const bf16x8 ah = w[((ks * MB + mb) * 3 + 0) * 64 + lane];
-            const bf16x8 am = w[((ks * MB + mb) * 3 + 1) * 64 + lane];
-            const bf16x8 al = w[((ks * MB + mb) * 3 + 2) * 64 + lane];
-            f32x16 c = acc[mb];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[ks], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[ks], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[ks], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], c, 0, 0, 0);
-            acc[mb] = c;
+    for (int it = 0; it < NK * MB; ++it) {
+        const int ks = it / MB, mb = it % MB;
+        bf16x8 nh = ah, nm = am, nl = al;
+        if (it + 1 < NK * MB) {
+            nh = w[((it + 1) * 3 + 0) * 64 + lane];
+            nm = w[((it + 1) * 3 + 1) * 64 + lane];
+            nl = w[((it + 1) * 3 + 2) * 64 + lane];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 c = acc[mb];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[ks], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[ks], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[ks], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], c, 0, 0, 0);
+        acc[mb] = c;
+        __builtin_amdgcn_sched_barrier(0);
+        ah = nh; am = nm; al = nl;
+    }
 }
-// One 160-wide layer in bf16x3: 5 phases, phase p consumes accumulator tile p of `in`.  Precondition: phase 0 of the
-// layer is in LDS buffer `cur` and a barrier has passed.  Each phase runs with the next phase (or `next`, the first
-// phase of the following layer) streaming global -> registers -> the other buffer.  `cur` flips once per phase.
-template <bool HAS_NEXT, bool ZERO = true>
-__device__ __forceinline__ void layer160_b3(float* lds, int& cur, const float* __restrict__ w,
-                                            const float* __restrict__ next, const Act& in, Act& out, int tid, int lane) {
-    if (ZERO) zero(out);
+// ---- weight-unit stream (staged by LDS-DMA).  Every chain is a fixed sequence of 30,720-B weight UNITS (a first layer,
+// one 32-feature K tile of a 160-wide layer, or the 3-output head).  A 256-thread workgroup (4 wavefronts, 128 rows)
+// walks the stream with a 2-slot LDS ring: while unit g is consumed from slot g&1, unit g+1 is DMA'd (global_load_lds)
+// straight into the other slot, which held unit g-1 - finished by every wavefront before the barrier that ended it.
+// One barrier per unit; the DMA has the whole unit (60 MFMAs per wavefront) to land and uses no staging registers.
+// Activations never cross wavefronts, so the units of consecutive layers simply follow each other.  Two workgroups
+// share a CU and cover each other's prologue and barrier waits.  (Measured alternatives: register staging per half
+// unit - prefetch window too short, waves parked 24 %; 8-wave workgroups with a 4-slot ring - no faster, every
+// prologue exposed.)
+constexpr int WGB = 256;                    // 4 wavefronts; two workgroups per CU cover each other's prologue / barriers
+constexpr int WGB_ROWS = 128;
+constexpr int NSLOT = 2;                    // LDS ring slots of one unit each (2 x 30,720 B per workgroup)
+constexpr int UNIT_FLOATS = PH_FLOATS;
+
+// global -> LDS DMA of one unit (30 pieces of 1 KB: each wave-instruction moves 64 lanes x 16 B to a wave-uniform LDS
+// base + lane*16).  Asynchronous: completion is awaited by the vmcnt(0) that __syncthreads() emits while a DMA is in
+// flight.  No staging registers, no ds_write.
+__device__ __forceinline__ void dma_unit(float* lds_slot, const float* __restrict__ src, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int p = 0; p < 5; ++p) {
-        const bool more = p < 4 || HAS_NEXT;
-        const float* nsrc = p < 4 ? w + (p + 1) * PH_FLOATS : next;
-        float* other = lds + (cur ^ 1) * PH_FLOATS;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {                       // one k-step at a time: 12 VGPRs of bf16 pieces and half a
-            Stager<PH_FLOATS / 2> s;                        // phase (16 VGPRs) of staging in flight
-            if (more) s.load(nsrc + u * (PH_FLOATS / 2), tid);
-            float x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = in.t[p][8 * u + j];
-            bf16x8 bh, bm, bl;
-            split8(x, bh, bm, bl);
-            mma_b3<1, 5>(lds + cur * PH_FLOATS + u * (5 * 3 * 64 * 4), &bh, &bm, &bl, out.t, lane);
-            if (more) s.store(other + u * (PH_FLOATS / 2), tid);
-        }
-        if (more) {
-            __syncthreads();
-            cur ^= 1;
+    for (int i = 0; i < (UNIT_FLOATS / 256 + WGB / 64 - 1) / (WGB / 64); ++i) {
+        const int piece = wave + (WGB / 64) * i;            // wave-uniform
+        if (piece < UNIT_FLOATS / 256) {
+            const float* gp = src + piece * 256 + lane * 4;
+            float* lp = lds_slot + piece * 256;
+            __builtin_amdgcn_global_load_lds(
+                reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(gp)),
+                reinterpret_cast<__attribute__((address_space(3))) void*>(static_cast<unsigned>(reinterpret_cast<uintptr_t>(lp))),
+                16, 0, 0);
         }
     }
+}
+// unit tables (indices into the bf16x3 image, WLB): kind 0 edge chain, 1 node encode, 2 propagate, 3 propagate + head
+template <int KIND> __device__ __forceinline__ constexpr int unit_of(int g) {
+    return KIND == 0 ? WLB::E_L1 + g
+         : KIND == 1 ? WLB::N_L1 + g
+         : KIND == 2 ? (g < 5 ? WLB::P_WB + g : g < 10 ? WLB::N_W2 + (g - 5) : WLB::N_W3 + (g - 10))
+                     : WLB::P_WB + g;
+}
+template <int KIND> struct UnitCount { static constexpr int N = KIND == 0 ? 16 : KIND == 1 ? 26 : KIND == 2 ? 15 : 16; };
+
+// consume unit G: prefetch G+2, run `body(wl)` on slot G&3, publish, barrier after odd units
+template <int KIND, int G, class Body>
+__device__ __forceinline__ void unit(float* lds, const float* __restrict__ W, int tid, Body body) {
+    constexpr int NU = UnitCount<KIND>::N;
+    // the other slot held unit G-1: every wavefront finished it before the barrier that ended that unit
+    if (G + 1 < NU) dma_unit(lds + ((G + 1) % NSLOT) * UNIT_FLOATS, W + unit_of<KIND>(G + 1) * UNIT_FLOATS, tid);
+    body(lds + (G % NSLOT) * UNIT_FLOATS);
+    if (G + 1 < NU) __syncthreads();                           // waits for this unit's DMA, then publishes it
+}
+template <int KIND>
+__device__ __forceinline__ void stream_begin(float* lds, const float* __restrict__ W, int tid) {
+    dma_unit(lds, W + unit_of<KIND>(0) * UNIT_FLOATS, tid);
+    __syncthreads();
+}
+// K tile T of a 160-wide layer: out += W[:, tile T] * in.t[T]   (two k-steps, 60 MFMAs)
+template <int T>
+__device__ __forceinline__ void tile_b3(const float* wl, const Act& in, Act& out, int lane) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = in.t[T][8 * u + j];
+        bf16x8 bh, bm, bl;
+        split8(x, bh, bm, bl);
+        mma_b3<1, 5>(wl + u * (5 * 3 * 64 * 4), &bh, &bm, &bl, out.t, lane);
+    }
+}
+// five consecutive units G0..G0+4 = one 160-wide layer
+template <int KIND, int G0>
+__device__ __forceinline__ void layer_b3(float* lds, const float* __restrict__ W, const Act& in, Act& out, int tid, int lane) {
+    unit<KIND, G0 + 0>(lds, W, tid, [&](const float* wl) { tile_b3<0>(wl, in, out, lane); });
+    unit<KIND, G0 + 1>(lds, W, tid, [&](const float* wl) { tile_b3<1>(wl, in, out, lane); });
+    unit<KIND, G0 + 2>(lds, W, tid, [&](const float* wl) { tile_b3<2>(wl, in, out, lane); });
+    unit<KIND, G0 + 3>(lds, W, tid, [&](const float* wl) { tile_b3<3>(wl, in, out, lane); });
+    unit<KIND, G0 + 4>(lds, W, tid, [&](const float* wl) { tile_b3<4>(wl, in, out, lane); });
 }
 // first layer from NF per-lane input features (zero beyond NF): k-step u, lane-half h, element j <-> feature 16u+8h+j
 template <int NK, int NF>
@@ -534,19 +593,15 @@ __device__ __forceinline__ void first_b3(const float* wl, const float* f, f32x16
     }
 }
 
-__global__ __launch_bounds__(WG, 2) void k_edge_enc_b3(GDev g) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * PH_FLOATS];
+__global__ __launch_bounds__(WGB, 2) void k_edge_enc_b3(GDev g) {
+    __shared__ __attribute__((aligned(16))) float lds[NSLOT * UNIT_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = (int)(blockIdx.x % (unsigned)g.B);
-    const int e0 = (int)(blockIdx.x / (unsigned)g.B) * WG_ROWS;
+    const int e0 = (int)(blockIdx.x / (unsigned)g.B) * WGB_ROWS;
     const int ne = g.n_ns ? g.n_ns[b] : g.n_edges[b];
     if (e0 >= ne) return;
     const float* W = g.wb3;
-    stage_now<PH_FLOATS>(lds, W + WLB::E_L1 * PH_FLOATS, tid);
-    int cur = 0;
-    Stager<PH_FLOATS> sn;
-    sn.load(W + WLB::E_L2 * PH_FLOATS, tid);
-
+    stream_begin<0>(lds, W, tid);
     const int t = e0 + wave * 32 + (lane & 31);
     const bool valid = t < ne;
     const int el = g.ns_edge ? g.ns_edge[(long)b * g.edge_cap + (valid ? t : 0)] : t;
@@ -572,31 +627,28 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc_b3(GDev g) {
     }
     Act x, y;
     zero(y);
-    first_b3<2, 18>(lds + cur * PH_FLOATS, f, y.t, lane);
-    sn.store(lds + (cur ^ 1) * PH_FLOATS, tid);
-    __syncthreads();
-    cur ^= 1;
+    unit<0, 0>(lds, W, tid, [&](const float* wl) { first_b3<2, 18>(wl, f, y.t, lane); });
     relu_one(y, lane);
-    layer160_b3<true>(lds, cur, W + WLB::E_L2 * PH_FLOATS, W + WLB::E_L3 * PH_FLOATS, y, x, tid, lane);
+    zero(x);
+    layer_b3<0, 1>(lds, W, y, x, tid, lane);
     relu_one(x, lane);
-    layer160_b3<true>(lds, cur, W + WLB::E_L3 * PH_FLOATS, W + WLB::E_W1 * PH_FLOATS, x, y, tid, lane);
+    zero(y);
+    layer_b3<0, 6>(lds, W, x, y, tid, lane);
     relu_one(y, lane);
-    layer160_b3<false>(lds, cur, W + WLB::E_W1 * PH_FLOATS, nullptr, y, x, tid, lane);
+    zero(x);
+    layer_b3<0, 11>(lds, W, y, x, tid, lane);
     store_rows(x, g.C, (long)b * g.c_cap + el, lane, valid);
 }
 
-__global__ __launch_bounds__(WG, 2) void k_node_enc_b3(GDev g) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * PH_FLOATS];
+__global__ __launch_bounds__(WGB, 2) void k_node_enc_b3(GDev g) {
+    __shared__ __attribute__((aligned(16))) float lds[NSLOT * UNIT_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long rend = g.row0 + g.nrows;
-    const long row = g.row0 + (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
+    const long row = g.row0 + (long)blockIdx.x * WGB_ROWS + wave * 32 + (lane & 31);
     const bool valid = row < rend;
     const long rowc = valid ? row : rend - 1;
     const float* W = g.wb3;
-    stage_now<PH_FLOATS>(lds, W + WLB::N_L1 * PH_FLOATS, tid);
-    int cur = 0;
-    Stager<PH_FLOATS> sn;
-    sn.load(W + WLB::N_L2 * PH_FLOATS, tid);
+    stream_begin<1>(lds, W, tid);
     float f[8];
     {
         const f32x4* p = reinterpret_cast<const f32x4*>(g.node_in + rowc * NODE_IN);
@@ -605,35 +657,37 @@ __global__ __launch_bounds__(WG, 2) void k_node_enc_b3(GDev g) {
     }
     Act x, y;
     zero(y);
-    first_b3<1, 8>(lds + cur * PH_FLOATS, f, y.t, lane);
-    sn.store(lds + (cur ^ 1) * PH_FLOATS, tid);
-    __syncthreads();
-    cur ^= 1;
+    unit<1, 0>(lds, W, tid, [&](const float* wl) { first_b3<1, 8>(wl, f, y.t, lane); });
     relu_one(y, lane);
-    layer160_b3<true>(lds, cur, W + WLB::N_L2 * PH_FLOATS, W + WLB::N_L3 * PH_FLOATS, y, x, tid, lane);
+    zero(x);
+    layer_b3<1, 1>(lds, W, y, x, tid, lane);
     relu_one(x, lane);
-    layer160_b3<true>(lds, cur, W + WLB::N_L3 * PH_FLOATS, W + WLB::N_WA * PH_FLOATS, x, y, tid, lane);
+    zero(y);
+    layer_b3<1, 6>(lds, W, x, y, tid, lane);
     relu_one(y, lane);
     store_rows(y, g.eff, row, lane, valid);
-    layer160_b3<true>(lds, cur, W + WLB::N_WA * PH_FLOATS, W + WLB::N_W2 * PH_FLOATS, y, x, tid, lane);
+    zero(x);
+    layer_b3<1, 11>(lds, W, y, x, tid, lane);
     store_rows(x, g.P, row, lane, valid);
-    layer160_b3<true>(lds, cur, W + WLB::N_W2 * PH_FLOATS, W + WLB::N_W3 * PH_FLOATS, y, x, tid, lane);
+    zero(x);
+    layer_b3<1, 16>(lds, W, y, x, tid, lane);
     store_rows(x, g.U, row, lane, valid);
-    layer160_b3<false>(lds, cur, W + WLB::N_W3 * PH_FLOATS, nullptr, y, x, tid, lane);
+    zero(x);
+    layer_b3<1, 21>(lds, W, y, x, tid, lane);
     store_rows(x, g.V, row, lane, valid);
 }
 
 template <bool LAST>
-__global__ __launch_bounds__(WG, 2) void k_node_prop_b3(GDev g) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * PH_FLOATS];
+__global__ __launch_bounds__(WGB, 2) void k_node_prop_b3(GDev g) {
+    __shared__ __attribute__((aligned(16))) float lds[NSLOT * UNIT_FLOATS];
+    constexpr int KIND = LAST ? 3 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long nrows = (long)g.B * g.N;
-    const long row = (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
+    const long row = (long)blockIdx.x * WGB_ROWS + wave * 32 + (lane & 31);
     const bool valid = row < nrows;
     const long rowc = valid ? row : nrows - 1;
     const float* W = g.wb3;
-    stage_now<PH_FLOATS>(lds, W + WLB::P_WB * PH_FLOATS, tid);
-    int cur = 0;
+    stream_begin<KIND>(lds, W, tid);
     Act x, y;
     const int pb = (int)(rowc / g.N), pi = (int)(rowc - (long)pb * g.N);
     const long crow = g.cls_on ? cls_row(g, pb, pi) : rowc;
@@ -643,35 +697,39 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop_b3(GDev g) {
     add_rows_part<0, 2>(y, ceff ? g.c_eff : g.eff, ceff ? crow : rowc, lane);
     materialize(y);
     add_rows_part<2, 5>(y, ceff ? g.c_eff : g.eff, (ceff ? crow : rowc) + pin_after(y), lane);
-    layer160_b3<true, false>(lds, cur, W + WLB::P_WB * PH_FLOATS, W + (LAST ? WLB::P_P0 : WLB::N_W2) * PH_FLOATS, x, y,
-                             tid, lane);
+    layer_b3<KIND, 0>(lds, W, x, y, tid, lane);            // y = P + eff + Wb*agg
     relu_one(y, lane);
     if (!LAST) {
         store_rows(y, g.eff, row, lane, valid);
-        layer160_b3<true>(lds, cur, W + WLB::N_W2 * PH_FLOATS, W + WLB::N_W3 * PH_FLOATS, y, x, tid, lane);
+        zero(x);
+        layer_b3<KIND, 5>(lds, W, y, x, tid, lane);
         store_rows(x, g.U, row, lane, valid);
-        layer160_b3<false>(lds, cur, W + WLB::N_W3 * PH_FLOATS, nullptr, y, x, tid, lane);
+        zero(x);
+        layer_b3<KIND, 10>(lds, W, y, x, tid, lane);
         store_rows(x, g.V, row, lane, valid);
     } else {
-        layer160_b3<true>(lds, cur, W + WLB::P_P0 * PH_FLOATS, W + WLB::P_P1 * PH_FLOATS, y, x, tid, lane);
+        zero(x);
+        layer_b3<KIND, 5>(lds, W, y, x, tid, lane);
         relu_one(x, lane);
-        layer160_b3<true>(lds, cur, W + WLB::P_P1 * PH_FLOATS, W + WLB::P_P2 * PH_FLOATS, x, y, tid, lane);
+        zero(y);
+        layer_b3<KIND, 10>(lds, W, x, y, tid, lane);
         relu_one(y, lane);
         f32x16 m[1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) m[0][r] = 0.0f;
+        unit<KIND, 15>(lds, W, tid, [&](const float* wl) {   // head: 10 k-steps, one m-block
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {                       // head: 10 k-steps, one m-block, all in one phase
+            for (int t = 0; t < 5; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float xx[8];
+                for (int u = 0; u < 2; ++u) {
+                    float xx[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xx[j] = y.t[t][8 * u + j];
-                bf16x8 bh, bm, bl;
-                split8(xx, bh, bm, bl);
-                mma_b3<1, 1>(lds + cur * PH_FLOATS + (2 * t + u) * (3 * 64 * 4), &bh, &bm, &bl, m, lane);
-            }
-        }
+                    for (int j = 0; j < 8; ++j) xx[j] = y.t[t][8 * u + j];
+                    bf16x8 bh, bm, bl;
+                    split8(xx, bh, bm, bl);
+                    mma_b3<1, 1>(wl + (2 * t + u) * (3 * 64 * 4), &bh, &bm, &bl, m, lane);
+                }
+        });
         const int b = pb, i = pi;
         if (valid && lane < 32 && i < g.n_p) {
             const float* curp = g.feat12 + rowc * F12 + 9;
@@ -701,6 +759,7 @@ static GDev to_dev(const float* w, const GraphBufs& g) {
     return d;
 }
 static int node_grid(const GraphBufs& g) { return (int)(((long)g.B * g.N + WG_ROWS - 1) / WG_ROWS); }
+static int node_grid_b3(const GraphBufs& g) { return (int)(((long)g.B * g.N + WGB_ROWS - 1) / WGB_ROWS); }
 
 hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
     const long rows = (long)g.B * g.c_cap;
@@ -715,7 +774,7 @@ hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
         (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 32, st);
         d.dbg = dbg;
     }
-    if (d.wb3) hipLaunchKernelGGL(k_edge_enc_b3, dim3(nwg), dim3(WG), 0, st, d);
+    if (d.wb3) hipLaunchKernelGGL(k_edge_enc_b3, dim3((unsigned)(rows / WGB_ROWS)), dim3(WGB), 0, st, d);
     else hipLaunchKernelGGL(k_edge_enc, dim3(nwg), dim3(WG), 0, st, d);
     if (probe_left > 0) {
         --probe_left;
@@ -742,14 +801,14 @@ hipError_t launch_node_enc(const float* w, const GraphBufs& g, long row0, long n
     }
     if (d.nrows <= 0) return hipSuccess;
     const dim3 grid((unsigned)((d.nrows + WG_ROWS - 1) / WG_ROWS));
-    if (d.wb3) hipLaunchKernelGGL(k_node_enc_b3, grid, dim3(WG), 0, st, d);
+    if (d.wb3) hipLaunchKernelGGL(k_node_enc_b3, dim3((unsigned)((d.nrows + WGB_ROWS - 1) / WGB_ROWS)), dim3(WGB), 0, st, d);
     else hipLaunchKernelGGL(k_node_enc, grid, dim3(WG), 0, st, d);
     return hipGetLastError();
 }
 hipError_t launch_node_prop(const float* w, const GraphBufs& g, int first_round, hipStream_t st) {
     GDev d = to_dev(w, g);
     d.first_round = first_round;
-    if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<false>, dim3(node_grid(g)), dim3(WG), 0, st, d);
+    if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<false>, dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
     else hipLaunchKernelGGL(k_node_prop<false>, dim3(node_grid(g)), dim3(WG), 0, st, d);
     return hipGetLastError();
 }
@@ -758,7 +817,7 @@ hipError_t launch_node_final(const float* w, const GraphBufs& g, int first_round
     GDev d = to_dev(w, g);
     d.first_round = first_round;
     d.clamp = clamp; d.pred_pos = pred_pos; d.pred_motion = pred_motion;
-    if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<true>, dim3(node_grid(g)), dim3(WG), 0, st, d);
+    if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<true>, dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
     else hipLaunchKernelGGL(k_node_prop<true>, dim3(node_grid(g)), dim3(WG), 0, st, d);
     return hipGetLastError();
 }

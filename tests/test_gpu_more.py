@@ -296,6 +296,7 @@ def test_bf16x3_mode_meets_the_same_bar(ag, dev, name, material):
     task = task_of(g)
     m = golden_model(ag, g, material, dev)
     s0, a = torch.from_numpy(g["state0"]).to(dev), torch.from_numpy(g["action"]).to(dev)
+    m.set_precision("fp32")                                            # whatever AG_PRECISION says
     exact = ag.dynamics(s0, a, m, dev, _ppm(task, material))["state_seqs"]
     m.set_precision("bf16x3")
     fast = ag.dynamics(s0, a, m, dev, _ppm(task, material))["state_seqs"]
