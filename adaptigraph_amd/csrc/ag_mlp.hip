@@ -13,8 +13,8 @@
 //     half h) is baked into the host-side weight packing (ag_api.hip: pack_layer).
 //   * Bias rides in the contraction: activation slot 150 is forced to 1.0, weight column 150 holds the bias.
 //   * The 160x152 weight panel of a layer (95 KB) is shared by the 4 wavefronts of a 256-thread workgroup through
-//     LDS, staged in four K-quarters so the next quarter streams global->registers->LDS underneath the MFMAs of
-//     the current one (two 25 KB buffers).  One ds_read_b128 feeds 4 MFMAs per m-block.  A workgroup is one
+//     LDS, staged in four K-quarters so the next quarter is DMA'd (global_load_lds) into the other buffer underneath
+//     the MFMAs of the current one (two 25 KB buffers, no staging registers).  One ds_read_b128 feeds 4 MFMAs per m-block.  A workgroup is one
 //     wavefront per SIMD and 50 KB of LDS, so TWO workgroups share a CU and run unsynchronised: the prologue
 //     gathers, mid-chain row loads, epilogue stores and barrier waits of one hide under the MFMAs of the other
 //     (measured: one 8-wave workgroup per CU left the MFMA pipe idle 18-41 % of the time).
@@ -61,6 +61,28 @@ struct Stager {
         }
     }
 };
+
+// global -> LDS DMA (global_load_lds, 16 B per lane): NFLOATS (a multiple of 256) in 1-KB pieces, each wave-instruction
+// writing 64 x 16 B at a wave-uniform LDS base + lane*16.  Asynchronous; awaited by the vmcnt(0) that __syncthreads()
+// emits while a DMA is in flight.  Uses no staging registers and no ds_write.
+template <int NFLOATS>
+__device__ __forceinline__ void dma_copy(float* lds_dst, const float* __restrict__ src, int tid) {
+    static_assert(NFLOATS % 256 == 0, "whole 1-KB pieces");
+    constexpr int NP = NFLOATS / 256, NW = WG / 64;
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < (NP + NW - 1) / NW; ++i) {
+        const int piece = wave + NW * i;                    // wave-uniform
+        if (piece < NP) {
+            const float* gp = src + piece * 256 + lane * 4;
+            float* lp = lds_dst + piece * 256;
+            __builtin_amdgcn_global_load_lds(
+                reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(gp)),
+                reinterpret_cast<__attribute__((address_space(3))) void*>(static_cast<unsigned>(reinterpret_cast<uintptr_t>(lp))),
+                16, 0, 0);
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ MFMA sweeps
 // chunks [Q0,Q1) of a layer whose LDS image starts at chunk Q0; input = previous accumulator tiles.
@@ -205,43 +227,24 @@ __device__ __forceinline__ void layer160(float* lds, const float* __restrict__ w
     float* b0 = lds;
     float* b1 = lds + BUF_FLOATS;
     if (ZERO) zero(out);                                     // else: accumulate on top of what `out` holds
-    {
-        Stager<Q_FLOATS> s;
-        s.load(w + Q_FLOATS, tid);
-        mma_act<0, QCH, 5>(b0, in, out.t, lane);
-        s.store(b1, tid);
-        __syncthreads();
-    }
-    {
-        Stager<Q_FLOATS> s;
-        s.load(w + 2 * Q_FLOATS, tid);
-        mma_act<QCH, 2 * QCH, 5>(b1, in, out.t, lane);
-        s.store(b0, tid);
-        __syncthreads();
-    }
-    {
-        Stager<Q3_FLOATS> s;
-        s.load(w + 3 * Q_FLOATS, tid);
-        mma_act<2 * QCH, 3 * QCH, 5>(b0, in, out.t, lane);
-        s.store(b1, tid);
-        __syncthreads();
-    }
-    {
-        Stager<NEXT> s;
-        if (NEXT > 0) s.load(next, tid);
-        mma_act<3 * QCH, KCH, 5>(b1, in, out.t, lane);
-        if (NEXT > 0) {
-            s.store(b0, tid);
-            __syncthreads();
-        }
-    }
+    // every sweep runs with the NEXT quarter's DMA in flight into the other buffer (free since the last barrier)
+    dma_copy<Q_FLOATS>(b1, w + Q_FLOATS, tid);
+    mma_act<0, QCH, 5>(b0, in, out.t, lane);
+    __syncthreads();
+    dma_copy<Q_FLOATS>(b0, w + 2 * Q_FLOATS, tid);
+    mma_act<QCH, 2 * QCH, 5>(b1, in, out.t, lane);
+    __syncthreads();
+    dma_copy<Q3_FLOATS>(b1, w + 3 * Q_FLOATS, tid);
+    mma_act<2 * QCH, 3 * QCH, 5>(b0, in, out.t, lane);
+    __syncthreads();
+    if (NEXT > 0) dma_copy<(NEXT > 0 ? NEXT : 256)>(b0, next, tid);
+    mma_act<3 * QCH, KCH, 5>(b1, in, out.t, lane);
+    if (NEXT > 0) __syncthreads();
 }
 
 template <int NFLOATS>
 __device__ __forceinline__ void stage_now(float* dst, const float* __restrict__ src, int tid) {
-    Stager<NFLOATS> s;
-    s.load(src, tid);
-    s.store(dst, tid);
+    dma_copy<NFLOATS>(dst, src, tid);
     __syncthreads();
 }
 
@@ -288,8 +291,7 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
 
     // small first-layer panel -> buffer 1; under its MFMAs, L2 half 0 -> buffer 0
     stage_now<EDGE_L1_CHUNKS * CHUNK_FLOATS_MB5>(lds + BUF_FLOATS, g.w + WL::E_L1, tid);
-    Stager<Q_FLOATS> sn;
-    sn.load(g.w + WL::E_L2, tid);
+    dma_copy<Q_FLOATS>(lds, g.w + WL::E_L2, tid);            // lands under the feature gather and the L1 sweep
 
     const int t = e0 + wave * 32 + (lane & 31);
     const bool valid = t < ne;
@@ -319,7 +321,6 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
     Act x, y;
     zero(y);
     mma_feat<EDGE_L1_CHUNKS>(lds + BUF_FLOATS, f, y.t, lane);
-    sn.store(lds, tid);
     __syncthreads();
     relu_one(y, lane);
     layer160<Q_FLOATS>(lds, g.w + WL::E_L2, g.w + WL::E_L3, y, x, tid, lane);
@@ -346,8 +347,7 @@ __global__ __launch_bounds__(WG, 2) void k_node_enc(GDev g) {
     const long rowc = valid ? row : rend - 1;
 
     stage_now<NODE_L1_CHUNKS * CHUNK_FLOATS_MB5>(lds + BUF_FLOATS, g.w + WL::N_L1, tid);
-    Stager<Q_FLOATS> sn;
-    sn.load(g.w + WL::N_L2, tid);
+    dma_copy<Q_FLOATS>(lds, g.w + WL::N_L2, tid);
     float f[8];
     {
         const f32x4* p = reinterpret_cast<const f32x4*>(g.node_in + rowc * NODE_IN);
@@ -357,7 +357,6 @@ __global__ __launch_bounds__(WG, 2) void k_node_enc(GDev g) {
     Act x, y;
     zero(y);
     mma_feat<NODE_L1_CHUNKS>(lds + BUF_FLOATS, f, y.t, lane);
-    sn.store(lds, tid);
     __syncthreads();
     relu_one(y, lane);
     layer160<Q_FLOATS>(lds, g.w + WL::N_L2, g.w + WL::N_L3, y, x, tid, lane);
@@ -386,22 +385,20 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     const bool valid = row < nrows;
     const long rowc = valid ? row : nrows - 1;
 
-    Stager<Q_FLOATS> sn;
-    sn.load(g.w + WL::P_WB, tid);
+    dma_copy<Q_FLOATS>(lds, g.w + WL::P_WB, tid);          // first quarter of Wb lands under the row loads
     Act x, y;
     // The residual terms seed the accumulator: y = P + eff, then y += Wb*agg.  All three row loads are issued here,
     // together, instead of two of them stalling the chain after the Wb layer.
     const int pb = (int)(rowc / g.N), pi = (int)(rowc - (long)pb * g.N);
     const long crow = g.cls_on ? cls_row(g, pb, pi) : rowc;
     const bool ceff = g.cls_on && g.first_round;             // round 1: the previous effect is p_enc itself
-    sn.store(lds, tid);                                      // frees the staging registers before the row loads
-    __syncthreads();
     load_rows(x, g.agg, rowc, lane);
     load_rows(y, g.cls_on ? g.c_P : g.P, crow, lane);
     // the third operand lands in temporaries: two batches keep it inside the register budget
     add_rows_part<0, 2>(y, ceff ? g.c_eff : g.eff, ceff ? crow : rowc, lane);
     materialize(y);
     add_rows_part<2, 5>(y, ceff ? g.c_eff : g.eff, (ceff ? crow : rowc) + pin_after(y), lane);
+    __syncthreads();                                         // Wb quarter 0 is in buffer 0
     layer160<Q_FLOATS, false>(lds, g.w + WL::P_WB, g.w + (LAST ? WL::P_P0 : WL::N_W2), x, y, tid, lane);
     relu_one(y, lane);                                       // y = new particle effect (slot 150 forced to 1)
     if (!LAST) {
