@@ -41,27 +41,6 @@ constexpr int Q3_FLOATS = (KCH - 3 * QCH) * CHUNK_FLOATS_MB5;
 struct Act { f32x16 t[5]; };
 
 // ------------------------------------------------------------------------------------------------ staging
-template <int NFLOATS>
-struct Stager {
-    static constexpr int N4 = NFLOATS / 4;
-    static constexpr int NV = (N4 + WG - 1) / WG;
-    f32x4 v[NV > 0 ? NV : 1];
-    __device__ __forceinline__ void load(const float* __restrict__ src, int tid) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = tid + i * WG;
-            if ((i + 1) * WG <= N4 || idx < N4) v[i] = reinterpret_cast<const f32x4*>(src)[idx];
-        }
-    }
-    __device__ __forceinline__ void store(float* dst, int tid) const {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = tid + i * WG;
-            if ((i + 1) * WG <= N4 || idx < N4) reinterpret_cast<f32x4*>(dst)[idx] = v[i];
-        }
-    }
-};
-
 // global -> LDS DMA (global_load_lds, 16 B per lane): NFLOATS (a multiple of 256) in 1-KB pieces, each wave-instruction
 // writing 64 x 16 B at a wave-uniform LDS base + lane*16.  Asynchronous; awaited by the vmcnt(0) that __syncthreads()
 // emits while a DMA is in flight.  Uses no staging registers and no ds_write.
@@ -152,7 +131,6 @@ __device__ __forceinline__ void relu_one(Act& a, int lane) {   // ReLU, then for
     a.t[4][10] = lane >= 32 ? 1.0f : a.t[4][10];
     materialize(a);
 }
-__device__ __forceinline__ void set_one(Act& a, int lane) { a.t[4][10] = lane >= 32 ? 1.0f : a.t[4][10]; }
 
 // row-major (pitch NFP) <-> accumulator layout.  Lane (j = lane&31, h = lane>>5) owns, of row j, the 16-byte
 // groups at feature 32t + 8q + 4h (registers 4q..4q+3 of tile t).
@@ -166,16 +144,6 @@ __device__ __forceinline__ void load_rows(Act& a, const float* __restrict__ base
             a.t[t][4 * q + 0] = v[0]; a.t[t][4 * q + 1] = v[1]; a.t[t][4 * q + 2] = v[2]; a.t[t][4 * q + 3] = v[3];
         }
 }
-__device__ __forceinline__ void add_rows(Act& a, const float* __restrict__ base, long row, int lane) {
-    const float* p = base + row * NFP + 4 * (lane >> 5);
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p + 32 * t + 8 * q);
-            a.t[t][4 * q + 0] += v[0]; a.t[t][4 * q + 1] += v[1]; a.t[t][4 * q + 2] += v[2]; a.t[t][4 * q + 3] += v[3];
-        }
-}
 // returns 0, but only after `v` has been computed, and the compiler cannot see that it is 0
 __device__ __forceinline__ long pin_after(Act& a) {
     int z = 0;
@@ -183,12 +151,6 @@ __device__ __forceinline__ long pin_after(Act& a) {
     asm volatile("" : "+v"(z), "+v"(v));
     a.t[0][0] = v;
     return z;
-}
-__device__ __forceinline__ void add_act(Act& a, const Act& b) {
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a.t[t][r] += b.t[t][r];
 }
 template <int T0, int T1>
 __device__ __forceinline__ void add_rows_part(Act& a, const float* __restrict__ base, long row, int lane) {
