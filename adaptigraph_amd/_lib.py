@@ -25,7 +25,8 @@ KERNEL_FAMILIES = ["edge_count", "edge_emit", "prep", "node_enc", "edge_enc", "m
 EXPORTS = ["ag_abi_version", "ag_ctx_create", "ag_ctx_destroy", "ag_last_error", "ag_ctx_load_weights",
            "ag_ctx_set_chunk", "ag_build_edges", "ag_forward", "ag_rollout", "ag_rollout_async",
            "ag_ctx_set_profiling", "ag_ctx_kernel_stats", "ag_ctx_reset_stats",
-           "ag_cost_chamfer", "ag_cost_state_stats", "ag_cost_penalty", "ag_ctx_set_precision", "ag_build_edges_single"]
+           "ag_cost_chamfer", "ag_cost_state_stats", "ag_cost_penalty", "ag_ctx_set_precision", "ag_build_edges_single",
+           "ag_edges_apply_tool_rule"]
 
 
 class AgDims(C.Structure):
@@ -65,6 +66,7 @@ def load():
     lib.ag_ctx_set_precision.argtypes = [vp, i32]
     lib.ag_build_edges.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp, i32, i32, i32, vp, vp, vp, vp]
     lib.ag_build_edges_single.argtypes = [vp, vp, vp, vp, vp, i32, f32, f32, i32, i32, i32, vp, vp, vp, vp]
+    lib.ag_edges_apply_tool_rule.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]
     lib.ag_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.ag_rollout.argtypes = [vp, vp, C.POINTER(AgRolloutParams), vp, vp, vp, vp, vp, vp, vp]  # ..., h_repeat, d_phys_vec, d_state_seqs
     lib.ag_rollout_async.argtypes = [vp, vp, C.POINTER(AgRolloutParams), vp, vp, vp, vp, vp, vp, vp, vp]

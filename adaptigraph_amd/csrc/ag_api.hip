@@ -507,6 +507,36 @@ int ag_build_edges_single(ag_ctx* c, void* stream, const float* d_pos, const uin
     return AG_OK;
 }
 
+int ag_edges_apply_tool_rule(ag_ctx* c, void* stream, const float* d_pos, const uint8_t* d_mask, const uint8_t* d_tool,
+                             int32_t N, int32_t n_tools, const int32_t* d_send_in, const int32_t* d_row_ptr_in,
+                             const uint8_t* d_subset, double kNN, int32_t edge_cap, int32_t* d_recv, int32_t* d_send,
+                             int32_t* d_row_ptr, int32_t* d_n_out) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_pos || !d_mask || !d_tool || !d_send_in || !d_row_ptr_in || !d_subset || !d_recv || !d_send || !d_row_ptr || !d_n_out)
+        return fail(c, AG_ERR_INVALID, "ag_edges_apply_tool_rule: null pointer");
+    if (N < 1 || n_tools < 0 || n_tools > N || edge_cap < 1)
+        return fail(c, AG_ERR_INVALID, "ag_edges_apply_tool_rule: bad sizes N=%d n_tools=%d edge_cap=%d", N, n_tools, edge_cap);
+    if (N > 4096) return fail(c, AG_ERR_UNSUPPORTED, "ag_edges_apply_tool_rule: N=%d exceeds 4096", N);
+    if (d_send_in == d_send || d_row_ptr_in == d_row_ptr)
+        return fail(c, AG_ERR_INVALID, "ag_edges_apply_tool_rule: input and output arrays must differ");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t pairs = (size_t)N * (size_t)std::max(1, n_tools);
+    int rc = ensure_slab(c, pairs * 6 + (size_t)(N + n_tools + 16) * 4 + 8 * 256);
+    if (rc) return rc;
+    RuleArgs a{};
+    a.pos = d_pos; a.mask = d_mask; a.tool = d_tool; a.subset = d_subset; a.send_in = d_send_in; a.row_ptr_in = d_row_ptr_in;
+    a.N = N; a.n_tools = n_tools; a.edge_cap = edge_cap; a.use_knn = (kNN < 1.0 && kNN > 0.0) ? 1 : 0; a.kNN = kNN;   // graph.py:156
+    a.tlist = c->slab.take<int>(std::max(1, n_tools));
+    a.misc = c->slab.take<int>(16);
+    a.pdis = c->slab.take<float>(pairs);
+    a.keep = c->slab.take<uint8_t>(pairs);
+    a.kept = c->slab.take<uint8_t>(pairs);
+    a.deg = c->slab.take<int>(N);
+    a.recv = d_recv; a.send = d_send; a.row_ptr = d_row_ptr; a.n_out = d_n_out;
+    HIPCHK(c, launch_tool_rule(a, static_cast<hipStream_t>(stream)));
+    return AG_OK;
+}
+
 int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_attrs, const float* d_action,
                const float* d_phys, const float* d_group, int32_t n_inst, const int32_t* d_recv, const int32_t* d_send,
                const int32_t* d_row_ptr, const int32_t* d_n_edges, int32_t edge_cap, int32_t B, int32_t N, int32_t n_p,

@@ -82,6 +82,15 @@ struct EdgeArgs {
 };
 hipError_t launch_edge_build(const EdgeArgs& a, hipStream_t st, void (*mark)(void*, int, int), void* mark_ctx);
 // list of non-self-loop edges per candidate (self-loop dedupe, see GraphBufs)
+// one tool-attachment rule of the single-graph builder applied to a CSR edge list (ag_rules.hip)
+struct RuleArgs {
+    const float* pos; const uint8_t* mask; const uint8_t* tool; const uint8_t* subset;
+    const int* send_in; const int* row_ptr_in;
+    int N, n_tools, edge_cap, use_knn; double kNN;
+    int* tlist; int* misc; float* pdis; uint8_t* keep; uint8_t* kept; int* deg;     // scratch
+    int* recv; int* send; int* row_ptr; int* n_out;
+};
+hipError_t launch_tool_rule(const RuleArgs& a, hipStream_t st);
 hipError_t launch_edge_nonself(const int* recv, const int* send, const int* row_ptr, int B, int N, int edge_cap,
                                int* ns_edge, int* n_ns, hipStream_t st);
 

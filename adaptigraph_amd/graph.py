@@ -110,15 +110,60 @@ def construct_edges_from_states_batch(states, adj_thresh, mask, tool_mask, topk=
     return el.to_dense()
 
 
+_PLANES = ["max_y", "min_x", "max_x", "min_z", "max_z"]            # graph.py:38 order
+
+
+def _plane_side(name, pos, max_y, max_x, max_z, min_x, min_z):
+    """graph.py:45-66 on particle vectors: which particles lie beyond the named bounding plane (torch's own
+    tensor-vs-scalar comparison, so the scalar is rounded exactly as in the reference)."""
+    if name == "max_y":
+        return pos[:, 1] >= max_y
+    if name == "max_x":
+        return pos[:, 0] >= max_x
+    if name == "max_z":
+        return pos[:, 2] >= max_z
+    if name == "min_x":
+        return pos[:, 0] <= min_x
+    if name == "min_z":
+        return pos[:, 2] <= min_z
+    raise Exception("Unknown plane for connecting tool to surface object particles!!")
+
+
+def _apply_tool_rule(eng, dev, el, pos, mask_u8, tool_u8, n_tools, subset, kNN):
+    """ag_edges_apply_tool_rule on a single-graph EdgeList -> new EdgeList."""
+    N = el.N
+    edge_cap = max(1, int(el.n_edges[0].item()) + N * n_tools)              # every rule adds at most N*M tool edges
+    recv = torch.empty((1, edge_cap), device=dev, dtype=torch.int32)
+    send = torch.empty((1, edge_cap), device=dev, dtype=torch.int32)
+    row_ptr = torch.empty((1, N + 1), device=dev, dtype=torch.int32)
+    n_edges = torch.empty((1,), device=dev, dtype=torch.int32)
+    sub_u8 = subset.to(dev).to(torch.bool).contiguous().view(torch.uint8)
+    eng.check(eng.lib.ag_edges_apply_tool_rule(eng.ctx, current_stream(dev), ptr(pos), ptr(mask_u8), ptr(tool_u8), N, n_tools,
+                                               ptr(el.send), ptr(el.row_ptr), ptr(sub_u8), float(kNN), edge_cap, ptr(recv),
+                                               ptr(send), ptr(row_ptr), ptr(n_edges)))
+    if int(n_edges[0].item()) < 0:
+        raise RuntimeError("internal: tool count passed to ag_edges_apply_tool_rule does not match tool_mask")
+    return EdgeList(recv, send, row_ptr, n_edges, N)
+
+
+def _tool_sender_edges(el, tool_b):
+    """adj[obj_tool_mask_2].sum() (graph.py:128-129, :178-179): edges whose sender is a tool particle.  (Receivers of
+    edges are valid particles by construction, which is the other half of obj_tool_mask_2.)"""
+    n = int(el.n_edges[0].item())
+    return int(tool_b[el.send[0, :n].long()].sum().item())
+
+
 def construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=10, connect_tools_all=False, max_y=None,
                                 min_y=None, max_x=None, max_z=None, min_x=None, min_z=None, connect_tools_surface=False,
                                 connect_tool_all_non_fixed=True, kNN=1.0, as_index=False):
-    """Drop-in for the single-graph builder (graph.py:68-231), default-argument path: states (N,3), mask/tool_mask (N,)
-    -> dense one-hot (Rr, Rs) of shape (n_rel, N) (or an EdgeList with as_index=True).  The tool-surface / kNN /
-    non-fixed-particle branches (graph.py:125-221) need max_y etc.; they are not implemented."""
-    if (connect_tool_all_non_fixed and max_y is not None and min_y is not None) or \
-            (connect_tools_surface and None not in (max_y, max_x, min_x, max_z, min_z)):
-        raise NotImplementedError("tool-surface / non-fixed-particle edge rules (graph.py:125-221) are not implemented")
+    """Drop-in for the single-graph builder (graph.py:68-231): states (N,3), mask/tool_mask (N,) -> dense one-hot
+    (Rr, Rs) of shape (n_rel, N) (or an EdgeList with as_index=True).
+
+    The radius / top-k / connect_tools_all part runs in ag_build_edges_single.  The two optional tool rules
+    (graph.py:125-171 'tool to all non-fixed particles' with its flat kNN filter, :173-221 'tool to the two closest
+    surface planes') are scalar decisions here - the same Python expressions as the reference, so thresholds round
+    the same way - followed by ag_edges_apply_tool_rule on the device.  Like the reference this path synchronises
+    (graph.py:129, :223)."""
     import numpy as np
     dev = _require_gpu(states.device)
     eng = default_engine(dev)
@@ -127,10 +172,11 @@ def construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=10, co
     thr = float(adj_thresh)
     thr2 = float(np.float32(thr * thr))                                     # double product, one fp32 rounding (:86,101)
     cull = float(np.nextafter(np.float32(abs(thr)), np.float32(np.inf)))    # cull^2 >= thr2 whatever the rounding did
-    mask_u8 = mask.to(dev).to(torch.bool).contiguous().view(torch.uint8)
-    tool_u8 = tool_mask.to(dev).to(torch.bool).contiguous().view(torch.uint8)
+    mask_b = mask.to(dev).to(torch.bool).contiguous()
+    tool_b = tool_mask.to(dev).to(torch.bool).contiguous()
+    mask_u8, tool_u8 = mask_b.view(torch.uint8), tool_b.view(torch.uint8)
     k = min(N, int(topk))
-    m = int(tool_mask.to(torch.bool).sum().item())
+    m = int(tool_b.sum().item())
     edge_cap = max(1, N * (k + m) if k < N else N * N)
     recv = torch.empty((1, edge_cap), device=dev, dtype=torch.int32)
     send = torch.empty((1, edge_cap), device=dev, dtype=torch.int32)
@@ -140,10 +186,63 @@ def construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=10, co
                                             cull, int(topk), int(bool(connect_tools_all)), edge_cap, ptr(recv), ptr(send),
                                             ptr(row_ptr), ptr(n_edges)))
     el = EdgeList(recv, send, row_ptr, n_edges, N)
+
+    if connect_tool_all_non_fixed and max_y is not None and min_y is not None:          # graph.py:125
+        check = _tool_sender_edges(el, tool_b)                                          # :128-129
+        threshold = (max_y - min_y) * 0.1 + min_y                                       # :134 bottom 10 % is fixed
+        if check > 0:
+            subset = (pos[:, 1] > threshold) & mask_b                                   # :138-143
+            el = _apply_tool_rule(eng, dev, el, pos, mask_u8, tool_u8, m, subset, kNN)  # :144-170
+
+    if connect_tools_surface and max_y is not None and max_x is not None and min_x is not None and max_z is not None \
+            and min_z is not None:                                                      # graph.py:173
+        check = _tool_sender_edges(el, tool_b)                                          # :178-179
+        if check > 0:
+            # :190-194 index s_receiv with the 0/1 VALUES of adj[obj_tool_mask_2]: each of its entries selects particle
+            # 0 or particle 1, broadcast over N senders.  Reproduced as written: n0 zeros, n1 ones.
+            n1 = check
+            n0 = int(mask_b.sum().item()) * m - check
+            p01 = pos[:2].cpu()
+            def plane_dist(axis, bound):
+                d = (p01[:, axis] - bound) ** 2                                         # fp32, like the reference
+                return N * (n0 * float(d[0]) + n1 * float(d[min(1, N - 1)]))
+            values = [plane_dist(1, max_y), plane_dist(0, min_x), plane_dist(0, max_x), plane_dist(2, min_z),
+                      plane_dist(2, max_z)]                                             # :36-37
+            order = np.argsort(values)                                                  # :39
+            first, second = _PLANES[order[0]], _PLANES[order[1]]
+            subset = _plane_side(first, pos, max_y, max_x, max_z, min_x, min_z) & \
+                _plane_side(second, pos, max_y, max_x, max_z, min_x, min_z) & mask_b     # :197-207
+            el = _apply_tool_rule(eng, dev, el, pos, mask_u8, tool_u8, m, subset, 1.0)  # :208-218
+
     if as_index:
         return el
     Rr, Rs = el.to_dense()
     return Rr[0], Rs[0]
+
+
+def construct_edges_with_backoff(states, adj_thresh, mask, tool_mask, topk, max_nR, knn_thresh=1.0, min_kNN=1.0,
+                                 knn_increment=0.1, **rules):
+    """The max_nR back-off loop the reference repeats around construct_edges_from_states (rollout.py:173-222,
+    rollout/graph.py:508-543, dataset.py:310-350): if the graph does not fit max_nR, first shrink the tool's kNN
+    fraction by knn_increment down to min_kNN, then lower top-k by one per attempt.  `rules` are the remaining keyword
+    arguments of construct_edges_from_states (connect_tools_all, max_y, ...).  Returns (Rr, Rs) padded to max_nR."""
+    Rr, Rs = construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=topk, kNN=knn_thresh, **rules)
+    kNN = knn_thresh
+    decrease_topK = topk
+    while True:
+        try:
+            return pad_torch(Rr, max_nR), pad_torch(Rs, max_nR)                          # rollout.py:192-194
+        except Exception as e:
+            if str(e) != "Exceeds max dims":
+                raise
+            if kNN <= min_kNN:                                                          # rollout.py:199-211
+                decrease_topK = decrease_topK - 1
+                if decrease_topK < 1:
+                    raise
+                Rr, Rs = construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=decrease_topK, kNN=kNN, **rules)
+            else:                                                                       # rollout.py:212-222
+                kNN = kNN - knn_increment
+                Rr, Rs = construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=topk, kNN=kNN, **rules)
 
 
 def pad_torch(x, max_dim, dim=0):

@@ -40,7 +40,7 @@ extern "C" {
 #define AG_ERR_UNSUPPORTED -4  /* configuration outside what the kernels implement                            */
 #define AG_ERR_NO_WEIGHTS -5   /* forward/rollout before ag_ctx_load_weights                                   */
 
-#define AG_ABI_VERSION 2
+#define AG_ABI_VERSION 3
 #define AG_NUM_WEIGHT_TENSORS 22
 
 typedef struct ag_ctx ag_ctx;
@@ -115,10 +115,26 @@ int ag_build_edges(ag_ctx* ctx, void* stream, const float* d_pos, const uint8_t*
  * threshold is formed in double precision and then rounded (h: thr2 = (float)((double)adj*adj), graph.py:86,101 - one ulp
  * away from the batch builder's fp32 square for e.g. 0.4); connect_tools_all is unconditional and leaves no
  * tool<->tool edge (graph.py:119-122).  cull_radius: any float with cull_radius^2 >= thr2 (e.g. nextafter(adj)).
- * The tool-surface / kNN / non-fixed-particle options of that function (max_y, kNN, ...) are not implemented. */
+ * The tool-surface / kNN / non-fixed-particle options of that function (max_y, kNN, ...) are applied afterwards, one
+ * rule at a time, with ag_edges_apply_tool_rule. */
 int ag_build_edges_single(ag_ctx* ctx, void* stream, const float* d_pos, const uint8_t* d_mask, const uint8_t* d_tool_mask,
                           int32_t N, float thr2, float cull_radius, int32_t topk, int32_t connect_tools_all,
                           int32_t edge_cap, int32_t* d_recv, int32_t* d_send, int32_t* d_row_ptr, int32_t* d_n_edges);
+
+/* One tool-attachment rule of construct_edges_from_states applied to an edge list produced by ag_build_edges_single
+ * (src/dynamics/dataset/graph.py:144-170 "tool to all non-fixed particles", :208-218 "tool to the closest surfaces").
+ * d_subset (N,) uint8 marks the rule's particle subset S (the kernel ANDs it with d_mask); forming S from max_y, the
+ * plane bounds etc. is scalar host arithmetic (graph.py:134-143, :190-207) and stays with the caller.  Effect:
+ *   edges (tool receiver <- sender in S) are removed; every (receiver in S <- tool) edge is present; if 0 < kNN < 1
+ *   only the keepK = (int)(kNN * #pairs) of those pairs with the smallest fp32 distance survive, ranked over the flat
+ *   row-major pair list, ties by pair position (graph.py:156-169); no tool<->tool edge remains.
+ * n_tools must equal the number of set entries of d_tool_mask (else *d_n_out = -1 and nothing else is written).
+ * Outputs like ag_build_edges_single: sorted by (receiver, sender); d_n_out is the TRUE count even when > edge_cap (then
+ * d_recv_out/d_send_out are not written).  Input and output arrays must not overlap. */
+int ag_edges_apply_tool_rule(ag_ctx* ctx, void* stream, const float* d_pos, const uint8_t* d_mask, const uint8_t* d_tool_mask,
+                             int32_t N, int32_t n_tools, const int32_t* d_send_in, const int32_t* d_row_ptr_in,
+                             const uint8_t* d_subset, double kNN, int32_t edge_cap, int32_t* d_recv_out, int32_t* d_send_out,
+                             int32_t* d_row_ptr_out, int32_t* d_n_out);
 
 /* Replaces DynamicsPredictor.forward (src/dynamics/gnn/model.py:130-342) on index-list graphs.
  *   d_state (B,n_his,N,3); d_attrs (B,N,2); d_action (B,N,3); d_phys (B,N) physics parameter per particle, zero

@@ -94,10 +94,35 @@ def construct_edges_single(pos, thr, mask, tool_mask, topk, connect_tools_all, c
     return recv.astype(np.int32), send.astype(np.int32)
 
 
-def construct_edges_from_states(pos, adj_thresh, mask, tool_mask, topk=10, connect_tools_all=False, check_ties=False):
-    """Default-argument path of the SINGLE-graph builder (graph.py:68-231; max_y etc. None, so :125-221 are inactive).
-    Differs from the batch builder in two reproduced ways: the threshold is squared in Python double precision and only
-    then meets the fp32 distances (:86,101), and connect_tools_all is unconditional with tool<->tool removed (:119-122)."""
+def _flat_smallest(values, k):
+    """torch.topk(values, k, largest=False) membership on a flat vector; ties resolved (value, index) lexicographic
+    (torch's own choice is implementation-defined; fixtures hold no such tie)."""
+    keep = np.zeros(values.shape[0], bool)
+    if k > 0:
+        keep[np.argsort(values, kind="stable")[:k]] = True
+    return keep
+
+
+PLANES = ["max_y", "min_x", "max_x", "min_z", "max_z"]      # graph.py:38 order, which np.argsort ties fall back on
+
+
+def _plane_masks(name, pos, max_y, max_x, max_z, min_x, min_z):
+    """graph.py:45-66: per-particle side of the plane test (the scalar is rounded to fp32 by torch's comparison)."""
+    axis, bound, ge = {"max_y": (1, max_y, True), "max_x": (0, max_x, True), "max_z": (2, max_z, True),
+                       "min_x": (0, min_x, False), "min_z": (2, min_z, False)}[name]
+    return pos[:, axis] >= F32(bound) if ge else pos[:, axis] <= F32(bound)
+
+
+def construct_edges_from_states(pos, adj_thresh, mask, tool_mask, topk=10, connect_tools_all=False, max_y=None, min_y=None,
+                                max_x=None, max_z=None, min_x=None, min_z=None, connect_tools_surface=False,
+                                connect_tool_all_non_fixed=True, kNN=1.0, check_ties=False, trace=None):
+    """The SINGLE-graph builder (graph.py:68-231).  Differs from the batch builder in two reproduced ways: the
+    threshold is squared in Python double precision and only then meets the fp32 distances (:86,101), and
+    connect_tools_all is unconditional with tool<->tool removed (:119-122).  With max_y/min_y given the
+    'tool to all non-fixed particles' rule (:125-171, optional flat kNN filter) applies, with all five bounds and
+    connect_tools_surface the 'tool to the two closest surface planes' rule (:173-221).  `trace` (dict) receives the
+    intermediate decisions (check values, chosen planes, keepK)."""
+    pos = np.ascontiguousarray(pos, dtype=F32)
     N = pos.shape[0]
     thr2 = F32(float(adj_thresh) * float(adj_thresh))               # :86 double product, rounded by the fp32 subtraction
     dis = pairwise_dis(pos)                                         # :87-88
@@ -106,6 +131,8 @@ def construct_edges_from_states(pos, adj_thresh, mask, tool_mask, topk=10, conne
     dis[~(mask[:, None] & mask[None, :])] = BIG                     # :89-92
     t12 = tool[:, None] & tool[None, :]
     dis[t12] = BIG                                                  # :93-96
+    m1 = tool[:, None] & mask[None, :]                              # :98 tool receiver, valid sender
+    m2 = tool[None, :] & mask[:, None]                              # :99 valid receiver, tool sender
     adj = (dis - thr2) < 0                                          # :101
     k = min(N, int(topk))                                           # :109
     if k < N:
@@ -116,9 +143,54 @@ def construct_edges_from_states(pos, adj_thresh, mask, tool_mask, topk=10, conne
             raise TopkTie("tie at the k-th boundary inside the radius")
         adj &= less | (eq & (np.cumsum(eq, axis=1) <= need))
     if connect_tools_all:                                           # :119-122
-        adj[tool[:, None] & mask[None, :]] = False
-        adj[tool[None, :] & mask[:, None]] = True
+        adj[m1] = False
+        adj[m2] = True
         adj[t12] = False
+    tr = trace if trace is not None else {}
+    if connect_tool_all_non_fixed and max_y is not None and min_y is not None:      # :125
+        check = int(adj[m2].sum())                                  # :128-129
+        threshold = (max_y - min_y) * 0.1 + min_y                   # :134 caller's own scalar types
+        tr["nonfixed_check"] = check
+        if check > 0:
+            surf = (pos[:, 1] > F32(threshold)) & mask              # :138-143 (fp32 comparison)
+            s1 = tool[:, None] & surf[None, :]                      # :144 tool receiver, non-fixed sender
+            s2 = tool[None, :] & surf[:, None]                      # :145 non-fixed receiver, tool sender
+            count = int(s2.sum())                                   # :151
+            tr["nonfixed_n"] = int(surf.sum())
+            adj[s1] = False                                         # :153
+            adj[s2] = True                                          # :154
+            if kNN < 1.0 and kNN > 0.0:                             # :156-169 flat k-nearest filter
+                keepK = int(kNN * count)
+                tr["keepK"] = keepK
+                adj[s2] = adj[s2] & _flat_smallest(dis[s2], keepK)
+            adj[t12] = False                                        # :170
+    if connect_tools_surface and None not in (max_y, max_x, min_x, max_z, min_z):   # :173
+        sel = adj[m2]                                               # :178 flat 0/1 vector
+        check = int(sel.sum())
+        tr["surface_check"] = check
+        if check > 0:
+            # :190-194 index s_receiv with the 0/1 VALUES of that vector: every entry selects particle 0 or 1,
+            # broadcast over N senders.  Reproduced as written.
+            n1 = check
+            n0 = sel.shape[0] - check
+            def plane_dist(axis, bound):
+                d0 = (float(pos[0, axis]) - float(F32(bound))) ** 2
+                d1 = (float(pos[1, axis]) - float(F32(bound))) ** 2
+                return N * (n0 * d0 + n1 * d1)
+            values = [plane_dist(1, max_y), plane_dist(0, min_x), plane_dist(0, max_x), plane_dist(2, min_z),
+                      plane_dist(2, max_z)]                         # :36-37 order
+            order = np.argsort(values)                              # :39
+            first, second = PLANES[order[0]], PLANES[order[1]]
+            tr["planes"] = (first, second)
+            c1 = _plane_masks(first, pos, max_y, max_x, max_z, min_x, min_z)
+            c2 = _plane_masks(second, pos, max_y, max_x, max_z, min_x, min_z)
+            surf = c1 & c2 & mask                                   # :201-207
+            tr["surface_n"] = int(surf.sum())
+            s1 = tool[:, None] & surf[None, :]
+            s2 = tool[None, :] & surf[:, None]
+            adj[s1] = False                                         # :216
+            adj[s2] = True                                          # :217
+            adj[t12] = False                                        # :218
     recv, send = np.nonzero(adj)                                    # :225
     return recv.astype(np.int32), send.astype(np.int32)
 

@@ -427,7 +427,7 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules"} & set(sys.argv)):
     main()
 
 
@@ -627,3 +627,116 @@ def gen_single_edges(name):
 
 if __name__ == "__main__" and "--single" in sys.argv:
     gen_single_edges("edges_single")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Row (f) rank 3, second half: the tool rules of the single-graph builder (graph.py:125-221) and the max_nR back-off
+# loop of the eval rollout (rollout.py:185-222).  3-D blobs: x/z grid, y spread so that the "bottom 10 % is fixed"
+# rule has something to cut.
+def blob(N_o, rng, pitch=0.1, height=0.3):
+    side = int(np.ceil(np.sqrt(N_o)))
+    g = grid_cloud(side, pitch, 0.02, rng)[:N_o]
+    g[:, 1] = rng.uniform(0.0, height, N_o).astype(np.float32)
+    return g
+
+
+def gen_single_rules(name):
+    import_reference()
+    from dynamics.dataset.graph import construct_edges_from_states
+    from dynamics.utils import pad_torch
+    rng = np.random.default_rng(91)
+    store, cases = {}, []
+    specs = [
+        # N_o, M, topk, thr, cta, nonfixed, kNN, surface, ratio (max_y = ratio * max y, rollout.py:132)
+        (150, 1, 10, 0.25, False, True, 1.0, False, 1.0),
+        (150, 1, 10, 0.25, True, True, 0.55, False, 1.0),
+        (180, 5, 8, 0.22, False, True, 0.3, False, 1.0),
+        (180, 5, 8, 0.22, True, True, 1.0, True, 0.8),
+        (120, 2, 6, 0.25, False, False, 1.0, True, 0.8),
+        (120, 2, 6, 0.25, False, True, 0.45, True, 0.7),
+        (-140, 1, 7, 0.25, False, False, 1.0, True, 0.9),    # negative N_o: object order reversed (particles 0/1 pick the planes)
+        (-140, 3, 7, 0.25, True, True, 0.6, True, 0.9),
+        (100, 1, 5, 0.05, False, True, 0.5, True, 0.8),      # tool out of reach: both checks are 0, rules inactive
+        (90, 3, 90, 0.3, True, True, 0.75, False, 1.0),      # topk >= N
+    ]
+    for ci, (N_o, M, topk, thr, cta, nonfixed, kNN, surface, ratio) in enumerate(specs):
+        flip, N_o = N_o < 0, abs(N_o)
+        N = N_o + M
+        states = np.zeros((N, 3), np.float32)
+        states[:N_o] = blob(N_o, rng)[::-1] if flip else blob(N_o, rng)
+        mask = np.ones(N, bool)
+        mask[N_o - 7:N_o - 3] = False
+        tool = np.zeros(N, bool)
+        tool[N_o:] = True
+        anchor = states[N_o // 2].copy()
+        for m in range(M):
+            states[N_o + m] = anchor + np.float32([0.03 * m + 0.01, 0.05, 0.02 * m + 0.015])
+        if thr < 0.1:
+            states[N_o:] += np.float32([0.0, 5.0, 0.0])
+        obj = states[:N_o][mask[:N_o]]
+        # bounds exactly as the eval rollout forms them (rollout.py:132-139): numpy float32 scalars
+        max_y = np.max(obj[:, 1]) * ratio
+        min_y = np.min(obj[:, 1])
+        max_x = np.max(obj[:, 0]) * ratio
+        max_z = np.max(obj[:, 2]) * ratio
+        min_x = np.min(obj[:, 0])
+        min_x = (max_x - min_x) * (1 - ratio) + min_x
+        min_z = np.min(obj[:, 2])
+        min_z = (max_z - min_z) * (1 - ratio) + min_z
+        kw = dict(topk=topk, connect_tools_all=cta, max_y=max_y, min_y=min_y, max_x=max_x, max_z=max_z, min_x=min_x,
+                  min_z=min_z, connect_tools_surface=surface, connect_tool_all_non_fixed=nonfixed, kNN=kNN)
+        ts, tm, tt = torch.from_numpy(states), torch.from_numpy(mask), torch.from_numpy(tool)
+        assert_no_topk_boundary_tie(ts[None], tm[None], tt[None], thr, topk)
+        Rr, Rs = quiet(construct_edges_from_states, ts, thr, tm, tt, **kw)
+        pre = f"case{ci}::"
+        store[pre + "states"], store[pre + "mask"], store[pre + "tool_mask"] = states, mask, tool
+        pack_edges(pre, edges_from_R(Rr[None], Rs[None]), store)
+        cases.append({"adj_thresh": thr, "topk": topk, "connect_tools_all": cta, "connect_tool_all_non_fixed": nonfixed,
+                      "kNN": kNN, "connect_tools_surface": surface,
+                      "bounds_f32": {k: float(v) for k, v in dict(max_y=max_y, min_y=min_y, max_x=max_x, min_x=min_x,
+                                                                  max_z=max_z, min_z=min_z).items()},
+                      "n_rel": int(Rr.shape[0])})
+    # ---- back-off loop (rollout.py:185-222): one case that needs kNN steps and then top-k steps
+    N_o, M, topk, thr = 160, 2, 9, 0.25
+    N = N_o + M
+    states = np.zeros((N, 3), np.float32)
+    states[:N_o] = blob(N_o, rng)
+    mask, tool = np.ones(N, bool), np.zeros(N, bool)
+    tool[N_o:] = True
+    states[N_o] = states[N_o // 2] + np.float32([0.01, 0.05, 0.015])
+    states[N_o + 1] = states[N_o // 2] + np.float32([0.04, 0.05, 0.035])
+    obj = states[:N_o]
+    bounds = dict(max_y=np.max(obj[:, 1]), min_y=np.min(obj[:, 1]), max_x=None, max_z=None, min_x=None, min_z=None)
+    ts, tm, tt = torch.from_numpy(states), torch.from_numpy(mask), torch.from_numpy(tool)
+    knn_thresh, min_kNN, knn_increment = 0.5, 0.2, 0.1
+    full = quiet(construct_edges_from_states, ts, thr, tm, tt, topk=topk, connect_tools_all=False, kNN=knn_thresh, **bounds)[0].shape[0]
+    lowest = quiet(construct_edges_from_states, ts, thr, tm, tt, topk=topk, connect_tools_all=False, kNN=0.2, **bounds)[0].shape[0]
+    max_nR = lowest - 150                                     # forces a few top-k reductions after kNN bottoms out
+    trail = []
+    Rr, Rs = quiet(construct_edges_from_states, ts, thr, tm, tt, topk=topk, connect_tools_all=False, kNN=knn_thresh, **bounds)
+    kNN, dec = knn_thresh, topk
+    while True:                                               # the loop of rollout.py:185-222, calling the reference
+        try:
+            Rr_p, Rs_p = pad_torch(Rr, max_nR), pad_torch(Rs, max_nR)
+            break
+        except Exception:
+            if kNN <= min_kNN:
+                dec -= 1
+                Rr, Rs = quiet(construct_edges_from_states, ts, thr, tm, tt, topk=dec, connect_tools_all=False, kNN=kNN, **bounds)
+            else:
+                kNN = kNN - knn_increment
+                Rr, Rs = quiet(construct_edges_from_states, ts, thr, tm, tt, topk=topk, connect_tools_all=False, kNN=kNN, **bounds)
+            trail.append([float(kNN), int(dec), int(Rr.shape[0])])
+    store["backoff::states"], store["backoff::mask"], store["backoff::tool_mask"] = states, mask, tool
+    pack_edges("backoff::", edges_from_R(Rr[None], Rs[None]), store)
+    meta = {"cases": cases, "backoff": {"adj_thresh": thr, "topk": topk, "knn_thresh": knn_thresh, "min_kNN": min_kNN,
+                                         "knn_increment": knn_increment, "max_nR": int(max_nR), "trail": trail,
+                                         "max_y": float(bounds["max_y"]), "min_y": float(bounds["min_y"]),
+                                         "first_n_rel": int(full)}}
+    store["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+    print(f"{name}: {[c['n_rel'] for c in cases]} back-off trail {trail} (max_nR {max_nR})")
+
+
+if __name__ == "__main__" and "--single-rules" in sys.argv:
+    gen_single_rules("edges_single_rules")

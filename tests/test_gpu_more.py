@@ -389,8 +389,6 @@ def test_single_graph_builder_vs_reference_golden(ag, dev):
         assert np.array_equal(r, wr) and np.array_equal(s, ws), ci
         Rr, Rs = ag.construct_edges_from_states(*args, topk=c["topk"], connect_tools_all=c["connect_tools_all"])
         assert Rr.shape == (len(wr), g[pre + "states"].shape[0]) and np.array_equal(Rr.argmax(-1).cpu().numpy(), wr)
-    with pytest.raises(NotImplementedError):
-        ag.construct_edges_from_states(*args, max_y=1.0, min_y=0.0)
     # last case: a pair at distance^2 == fp32(0.16) exactly, adj_thresh 0.4.  The single-graph builder (double-precision
     # square) leaves it unconnected; the batch builder (fp32 square = 0.16000001) connects it (SURVEY a5'(ii)).
     assert len(wr) == 3
@@ -422,3 +420,78 @@ def test_mixed_variable_size_graphs_masked(ag, O, dev, material, n_max, cloud_fn
     want = O.dynamics_masked(W, 3, state, mask, a, task)
     err = np.abs(out["state_seqs"].cpu().numpy() - want["state_seqs"]).max()
     assert err <= POS_TOL, err
+
+
+def _rule_kwargs(c):
+    kw = {k: np.float32(v) for k, v in c["bounds_f32"].items()}        # numpy float32 scalars, as the eval rollout passes
+    kw.update(topk=c["topk"], connect_tools_all=c["connect_tools_all"], connect_tools_surface=c["connect_tools_surface"],
+              connect_tool_all_non_fixed=c["connect_tool_all_non_fixed"], kNN=c["kNN"])
+    return kw
+
+
+def test_single_graph_tool_rules_vs_reference_golden(ag, dev):
+    """SURVEY 8(f) rank 3, second half: the tool rules of construct_edges_from_states (graph.py:125-221) - non-fixed
+    particles, flat kNN filter, two closest surface planes - bit-exact against the reference's own output."""
+    import json
+    from helpers import load_golden, split_edges
+    g = load_golden("edges_single_rules")
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    for ci, c in enumerate(meta["cases"]):
+        pre = f"case{ci}::"
+        args = (torch.from_numpy(g[pre + "states"]).to(dev), c["adj_thresh"], torch.from_numpy(g[pre + "mask"]).to(dev),
+                torch.from_numpy(g[pre + "tool_mask"]).to(dev))
+        el = ag.construct_edges_from_states(*args, as_index=True, **_rule_kwargs(c))
+        (r, s), = _edges_to_lists(el)
+        (wr, ws), = split_edges(g, pre)
+        assert np.array_equal(r, wr) and np.array_equal(s, ws), ci
+        rp = el.row_ptr[0].cpu().numpy()
+        assert rp[0] == 0 and rp[-1] == len(wr) and np.array_equal(np.diff(rp), np.bincount(wr, minlength=el.N))
+        Rr, Rs = ag.construct_edges_from_states(*args, **_rule_kwargs(c))
+        assert Rr.shape == (c["n_rel"], g[pre + "states"].shape[0])
+        assert np.array_equal(Rs.argmax(-1).cpu().numpy(), ws)
+
+
+def test_single_graph_tool_rules_vs_oracle_sweep(ag, O, dev):
+    """Random blobs over the rule switches (incl. tools in the middle of the index range and invalid particles)."""
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        N_o, M = int(rng.integers(40, 400)), int(rng.integers(1, 6))
+        N = N_o + M
+        pos = rng.uniform(0, 1, (N, 3)).astype(np.float32) * np.float32([1.0, 0.3, 1.0])
+        tool = np.zeros(N, bool)
+        tool[rng.choice(N, M, replace=False)] = True                    # tools anywhere in the index range
+        mask = rng.uniform(size=N) > 0.05
+        mask[tool] = True
+        obj = pos[mask & ~tool]
+        kw = dict(topk=int(rng.integers(3, 12)), connect_tools_all=bool(trial & 1), kNN=float(rng.choice([1.0, 0.7, 0.35, 0.05])),
+                  connect_tool_all_non_fixed=bool(trial % 3), connect_tools_surface=bool(trial % 4 < 2),
+                  max_y=np.max(obj[:, 1]) * 0.8, min_y=np.min(obj[:, 1]), max_x=np.max(obj[:, 0]) * 0.8,
+                  min_x=np.min(obj[:, 0]) + 0.2, max_z=np.max(obj[:, 2]) * 0.8, min_z=np.min(obj[:, 2]) + 0.2)
+        thr = float(rng.choice([0.12, 0.2, 0.3]))
+        wr, ws = O.construct_edges_from_states(pos, thr, mask, tool, check_ties=True, **kw)
+        el = ag.construct_edges_from_states(torch.from_numpy(pos).to(dev), thr, torch.from_numpy(mask).to(dev),
+                                            torch.from_numpy(tool).to(dev), as_index=True, **kw)
+        (r, s), = _edges_to_lists(el)
+        assert np.array_equal(r, wr) and np.array_equal(s, ws), (trial, kw)
+
+
+def test_backoff_loop_vs_reference_golden(ag, dev):
+    """rollout.py:185-222: kNN shrinks by knn_increment to min_kNN, then top-k drops, until the graph fits max_nR."""
+    import json
+    from helpers import load_golden, split_edges
+    g = load_golden("edges_single_rules")
+    b = json.loads(bytes(g["meta_json"]).decode())["backoff"]
+    args = (torch.from_numpy(g["backoff::states"]).to(dev), b["adj_thresh"], torch.from_numpy(g["backoff::mask"]).to(dev),
+            torch.from_numpy(g["backoff::tool_mask"]).to(dev))
+    Rr, Rs = ag.construct_edges_with_backoff(*args, topk=b["topk"], max_nR=b["max_nR"], knn_thresh=b["knn_thresh"],
+                                             min_kNN=b["min_kNN"], knn_increment=b["knn_increment"],
+                                             max_y=np.float32(b["max_y"]), min_y=np.float32(b["min_y"]))
+    (wr, ws), = split_edges(g, "backoff::")
+    assert Rr.shape == (b["max_nR"], g["backoff::states"].shape[0])
+    n = len(wr)
+    assert n == b["trail"][-1][2]
+    assert np.array_equal(Rr[:n].argmax(-1).cpu().numpy(), wr) and np.array_equal(Rs[:n].argmax(-1).cpu().numpy(), ws)
+    assert float(Rr[n:].abs().sum()) == 0.0 and float(Rs[n:].abs().sum()) == 0.0
+    with pytest.raises(Exception, match="Exceeds max dims"):            # nothing left to shrink: the reference's loop dies the same way
+        ag.construct_edges_with_backoff(*args, topk=1, max_nR=3, knn_thresh=0.1, min_kNN=0.2,
+                                        max_y=np.float32(b["max_y"]), min_y=np.float32(b["min_y"]))

@@ -120,3 +120,50 @@ def test_single_graph_builder_vs_reference():
                                              c["topk"], c["connect_tools_all"])
         (wr, ws), = split_edges(g, pre)
         assert np.array_equal(r, wr) and np.array_equal(s, ws), ci
+
+
+def _rule_kwargs(c):
+    kw = {k: np.float32(v) for k, v in c["bounds_f32"].items()}        # numpy float32 scalars, as the eval rollout passes
+    kw.update(topk=c["topk"], connect_tools_all=c["connect_tools_all"], connect_tools_surface=c["connect_tools_surface"],
+              connect_tool_all_non_fixed=c["connect_tool_all_non_fixed"], kNN=c["kNN"])
+    return kw
+
+
+def test_single_graph_tool_rules_vs_reference():
+    """graph.py:125-221: non-fixed-particle rule, flat kNN filter, two-closest-surface-planes rule, and both in sequence."""
+    import json
+    g = load_golden("edges_single_rules")
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    seen = set()
+    for ci, c in enumerate(meta["cases"]):
+        pre = f"case{ci}::"
+        tr = {}
+        r, s = O.construct_edges_from_states(g[pre + "states"], c["adj_thresh"], g[pre + "mask"], g[pre + "tool_mask"],
+                                             trace=tr, **_rule_kwargs(c))
+        (wr, ws), = split_edges(g, pre)
+        assert np.array_equal(r, wr) and np.array_equal(s, ws), (ci, tr)
+        seen |= set(tr)
+    assert {"nonfixed_check", "keepK", "surface_check", "planes"} <= seen
+
+
+def test_backoff_loop_vs_reference():
+    """rollout.py:185-222 replayed with the oracle builder: same trail of (kNN, topk, n_rel), same final graph."""
+    import json
+    g = load_golden("edges_single_rules")
+    b = json.loads(bytes(g["meta_json"]).decode())["backoff"]
+    args = (g["backoff::states"], b["adj_thresh"], g["backoff::mask"], g["backoff::tool_mask"])
+    bounds = dict(max_y=np.float32(b["max_y"]), min_y=np.float32(b["min_y"]))
+    kNN, dec, trail = b["knn_thresh"], b["topk"], []
+    r, s = O.construct_edges_from_states(*args, topk=b["topk"], kNN=kNN, **bounds)
+    assert len(r) == b["first_n_rel"]
+    while len(r) > b["max_nR"]:
+        if kNN <= b["min_kNN"]:
+            dec -= 1
+            r, s = O.construct_edges_from_states(*args, topk=dec, kNN=kNN, **bounds)
+        else:
+            kNN = kNN - b["knn_increment"]
+            r, s = O.construct_edges_from_states(*args, topk=b["topk"], kNN=kNN, **bounds)
+        trail.append([float(kNN), int(dec), len(r)])
+    assert trail == b["trail"]
+    (wr, ws), = split_edges(g, "backoff::")
+    assert np.array_equal(r, wr) and np.array_equal(s, ws)
