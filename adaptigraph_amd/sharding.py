@@ -18,12 +18,41 @@ def shard_bounds(n_candidates: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_costs(cost_local: torch.Tensor, n_candidates: int, group=None) -> torch.Tensor:
-    """cost_local: (hi-lo,) costs of this rank's shard -> (n_candidates,) costs of the whole batch on every rank."""
+def shard_bounds_weighted(weights, world: int, rank: int):
+    """Contiguous shards of a RAGGED batch balanced by work instead of by count (for mixed-size graphs
+    the work of a candidate is proportional to its edge count, or to N_b * (topk + M) before the graph exists).
+    Cut r lies where the running sum first reaches r/world of the total (nearest candidate boundary); every rank
+    computes the same cuts from the same `weights`, so no exchange is needed."""
+    import numpy as np
+    w = np.asarray(weights, dtype=np.float64)
+    assert w.ndim == 1 and (w >= 0).all()
+    n = w.shape[0]
+    csum = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for r in range(1, world):
+        target = csum[-1] * r / world
+        i = int(np.searchsorted(csum, target))                      # first boundary with csum >= target
+        if i > 0 and target - csum[i - 1] <= csum[min(i, n)] - target:
+            i -= 1                                                  # the boundary before it is closer
+        cuts.append(min(n, max(cuts[-1], i)))
+    cuts.append(n)
+    return cuts[rank], cuts[rank + 1]
+
+
+def all_gather_costs(cost_local: torch.Tensor, n_candidates: int, group=None, bounds=None) -> torch.Tensor:
+    """cost_local: (hi-lo,) costs of this rank's shard -> (n_candidates,) costs of the whole batch on every rank.
+    bounds: optional list of (lo, hi) per rank for work-balanced shards (default: shard_bounds)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         assert cost_local.numel() == n_candidates
         return cost_local
     world = dist.get_world_size(group)
+    if bounds is not None:
+        per = max(hi - lo for lo, hi in bounds)
+        padded = torch.zeros(per, device=cost_local.device, dtype=cost_local.dtype)
+        padded[:cost_local.numel()] = cost_local
+        out = torch.empty(per * world, device=cost_local.device, dtype=cost_local.dtype)
+        dist.all_gather_into_tensor(out, padded, group=group)
+        return torch.cat([out[r * per: r * per + (hi - lo)] for r, (lo, hi) in enumerate(bounds)])
     per = (n_candidates + world - 1) // world
     padded = torch.zeros(per, device=cost_local.device, dtype=cost_local.dtype)
     padded[:cost_local.numel()] = cost_local
@@ -38,11 +67,18 @@ def all_gather_costs(cost_local: torch.Tensor, n_candidates: int, group=None) ->
     return torch.cat(pieces)
 
 
-def sharded_rollout_costs(rollout_fn, cost_fn, actions: torch.Tensor, group=None):
+def sharded_rollout_costs(rollout_fn, cost_fn, actions: torch.Tensor, group=None, weights=None):
     """Run `rollout_fn(actions[lo:hi])` on this rank's shard, reduce it to per-candidate costs with `cost_fn`, and
-    return the full (B,) cost vector on every rank.  `actions` is the FULL (B, H, 4) batch, identical on all ranks."""
+    return the full (B,) cost vector on every rank.  `actions` is the FULL (B, H, 4) batch, identical on all ranks.
+    weights: optional per-candidate work estimate (ragged batches) -> work-balanced shards; the callbacks then take
+    (lo, hi) as extra arguments since per-candidate inputs other than the actions must be sliced too."""
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
-    lo, hi = shard_bounds(actions.shape[0], world, rank)
-    local = cost_fn(rollout_fn(actions[lo:hi]))
-    return all_gather_costs(local, actions.shape[0], group)
+    if weights is None:
+        lo, hi = shard_bounds(actions.shape[0], world, rank)
+        local = cost_fn(rollout_fn(actions[lo:hi]))
+        return all_gather_costs(local, actions.shape[0], group)
+    bounds = [shard_bounds_weighted(weights, world, r) for r in range(world)]
+    lo, hi = bounds[rank]
+    local = cost_fn(rollout_fn(actions[lo:hi], lo, hi), lo, hi)
+    return all_gather_costs(local, actions.shape[0], group, bounds=bounds)
