@@ -32,6 +32,7 @@ FLOP_PER_NODE_ENC = 2 * (6 * 150 + 2 * 150 * 150) + 3 * 2 * 150 * 150           
 FLOP_PER_NODE_PROP = 3 * 2 * 150 * 150                                             # Wb + W2 + W3 (per round)
 FLOP_PER_NODE_FINAL = 2 * 150 * 150 + 2 * (2 * 150 * 150 + 3 * 150)                # Wb + predictor
 PEAK_FP32_MFMA_TFLOPS = 157.3                                                      # MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0                                                              # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def random_weights(seed, nf=150, in_dim=6, rel_dim=17):
@@ -194,7 +195,7 @@ def main():
     # ---- roofline pass: the same rollout once more with HIP events around every launch of the profiled kernels, on
     # the stream they are launched on.  Profiling pins the engine to ONE stream: with two chunks sharing the GPU an
     # event-bracketed duration measures the neighbour's kernels too.
-    fams = [] if args.no_kernel_profile else ["edge_enc"] if not args.profile_all else [
+    fams = [] if args.no_kernel_profile else ["edge_enc", "mp"] if not args.profile_all else [
         "edge_count", "edge_emit", "node_enc", "edge_enc", "mp", "node_prop", "node_final", "roll_init", "roll_update",
         "cost"]
     prof_steps = 1
@@ -269,6 +270,15 @@ def main():
             if abs(tj["edges_per_launch"] - edges_per_launch) / edges_per_launch < 0.01:
                 traffic = tj["hbm_bytes_per_launch"]
         achieved = FLOP_PER_EDGE * edges_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        # second-largest family, the HBM-bound one: k_mp.  Compulsory HBM bytes per candidate and message-passing
+        # round: one 640-B C row per encoded edge and a 4-B index per edge, streamed once; the U and
+        # V tables in and agg out, 640 B per particle each (the per-edge V gathers re-read the V table out of L2).
+        # Three rounds per rollout step.
+        ms_mp, n_mp = fam_ms.get("mp", (0.0, 0))
+        mp_bytes_round = E_enc * 640 + E * 4 + (N_o + 1) * 1920
+        mp_bytes_launch = mp_bytes_round * (hi - lo) * H * R * 3 / max(1, n_mp // prof_steps)
+        mp_avg_ms = ms_mp / max(1, n_mp)
+        mp_gbs = mp_bytes_launch / (mp_avg_ms * 1e-3) / 1e9 if mp_avg_ms > 0 else 0.0
         line = {
             "metric": "rollout-steps/sec", "value": total_steps * args.steps / dt, "unit": "rollout-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -284,6 +294,12 @@ def main():
                          "measured": "HIP events on the launch stream, 1 extra rollout after the timed region with the "
                                      "engine pinned to one stream",
                          "flop_per_edge": FLOP_PER_EDGE, "edges_per_launch": edges_per_launch},
+            "roofline_hbm_kernel": {"bound": "hbm", "kernel": "k_mp", "achieved": mp_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": mp_gbs / PEAK_HBM_GBS, "avg_launch_ms": mp_avg_ms, "launches": int(n_mp),
+                                    "bytes_per_launch": mp_bytes_launch, "traffic": 859.2e6,
+                                    "note": "second-largest kernel family; achieved = compulsory HBM bytes / HIP-event "
+                                            "time; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE per launch "
+                                            "(profiles/r01_pmc_summary.md): gathered V rows that miss L2 are the excess"},
             "kernel_ms_per_rollout_single_stream": {f: v[0] / prof_steps for f, v in fam_ms.items()},
         }
         if dt_b3 is not None:
