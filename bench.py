@@ -126,12 +126,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # Rehearsal hooks (never set by the driver): AG_BENCH_SHARE_GPU=1 maps every rank onto the GPUs that exist (two
+    # ranks on a one-GPU box) and AG_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device.
+    if os.environ.get("AG_BENCH_SHARE_GPU") == "1":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("AG_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import adaptigraph_amd as ag
 
