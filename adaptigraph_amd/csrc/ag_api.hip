@@ -607,7 +607,13 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
 
     const int k = std::min(N, p->topk);
     const long bound = (long)N * (k + p->M);                 // in-degree <= topk + M (radius-AND-top-k, then tool rule)
-    const int edge_cap = (int)round_up((size_t)std::min<long>(bound, p->max_nR), 256);
+    // Fast path (top-k active; the rollout keeps its tool particles behind the object particles): the count kernel's
+    // per-row sender lists are used as the graph, slot-indexed (EdgeArgs::ell_full) - no emit pass, no CSR copy.
+    // Every row then owns topk + M slots whatever max_nR is (the max_nR rule is applied by k_ell_index).
+    static const bool ell_env = !(getenv("AG_NO_ELL_GRAPH") && atoi(getenv("AG_NO_ELL_GRAPH")));
+    static const bool dedupe_env = !(getenv("AG_NO_SELF_DEDUPE") && atoi(getenv("AG_NO_SELF_DEDUPE")));
+    const bool ell_full = ell_env && dedupe_env && k < N;
+    const int edge_cap = (int)round_up((size_t)(ell_full ? bound : std::min<long>(bound, p->max_nR)), 256);
     int ns = std::max(1, std::min(c->n_streams, (int)ag_ctx::kMaxStreams));
     if (const char* e = getenv("AG_STREAMS")) ns = std::max(1, std::min(atoi(e), (int)ag_ctx::kMaxStreams));
     if (c->prof_mask) ns = 1;   // per-kernel event times are only meaningful without cross-stream interference
@@ -666,6 +672,11 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         ea.slices = slices; ea.ell = w.ell; ea.deg = w.deg; ea.slice_tot = w.slice_tot; ea.cta_flag = w.cta_flag;
         ea.recv = w.recv; ea.send = w.send; ea.row_ptr = w.row_ptr; ea.n_edges = w.n_edges;
         ea.overflow = d_overflow_flag; ea.max_nR = p->max_nR; ea.zero_on_overflow = 1;
+        if (ell_full) {
+            ea.ell_full = 1; ea.ell = w.send; ea.ell_stride = k + p->M; ea.ell_bstride = edge_cap;
+            ea.ns_edge = w.ns_edge; ea.n_ns = w.n_ns;
+            g.deg = w.deg; g.ell_stride = k + p->M;
+        }
         for (int li = 0; li < p->H; ++li) {
             int max_rep = 0;
             for (int b = 0; b < nb; ++b) max_rep = std::max(max_rep, h_repeat[(size_t)(b0 + b) * p->H + li]);
@@ -681,7 +692,7 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
             obj_cls_ready[ci % ns] = true;
             for (int ai = 1; ai <= max_rep; ++ai) {           // forward_dynamics.py:156
                 HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));
-                if (g.ns_edge) { Scoped s(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, nb, N, edge_cap, w.ns_edge, w.n_ns, cs)); }
+                if (g.ns_edge && !ell_full) { Scoped s(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, nb, N, edge_cap, w.ns_edge, w.n_ns, cs)); }
                 rc = run_model(c, g, w.r.pred, w.r.motion, cs);
                 if (rc) return rc;
                 ra.ai = ai;

@@ -79,6 +79,13 @@ struct EdgeArgs {
     int* overflow;              // single int: max edge count seen above max_nR (atomicMax), may be null
     int max_nR;
     int zero_on_overflow;       // internal rollout use: present an EMPTY graph downstream when E > edge_cap
+    // Rollout fast path (top-k active, tool particles behind the object particles): the per-row sender lists ARE the
+    // graph.  `ell` then points at the `send` array, a row owns `ell_stride` = topk + M slots (kept senders ascending,
+    // then the tool senders of the connect_tools_all rule), a candidate `ell_bstride` = edge_cap slots; slot ids
+    // replace CSR edge ids, `deg` replaces row_ptr, and k_edge_emit is skipped.  k_ell_index writes recv per slot,
+    // the non-self-loop slot list (ns_edge, n_ns), n_edges, and applies the max_nR rule.
+    int ell_full; int ell_stride; long ell_bstride;   // 0 / unset: ell_stride = min(topk,N), ell_bstride = N*ell_stride
+    int* ns_edge; int* n_ns;
 };
 hipError_t launch_edge_build(const EdgeArgs& a, hipStream_t st, void (*mark)(void*, int, int), void* mark_ctx);
 // list of non-self-loop edges per candidate (self-loop dedupe, see GraphBufs)
@@ -103,6 +110,8 @@ struct GraphBufs {
     float* P; float* U; float* V; float* agg;
     float* C;         // (B*c_cap, NFP)  W1*rel_enc + b_rp
     const int* recv; const int* send; const int* row_ptr; const int* n_edges;
+    const int* deg; int ell_stride;   // ell_stride > 0: slot-indexed graph of the rollout fast path (row i owns slots
+                                      // [i*ell_stride, i*ell_stride + deg[i]) of send / C), row_ptr unused
     int B, N, n_p, n_inst;
     int edge_cap;     // pitch of recv/send per candidate
     int c_cap;        // pitch of C per candidate, multiple of 256

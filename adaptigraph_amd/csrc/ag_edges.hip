@@ -47,6 +47,8 @@ struct EdgeDev {
     float thr2_override; int use_thr2;   // single-graph builder: threshold squared in double, then rounded (graph.py:86,101)
     int B, N, k, topk_active, cta, edge_cap, slices, rows_per_slice;
     int* ell;                            // (B, N, k) kept non-merged senders per row (top-k active only)
+    int ell_full, ell_stride; long ell_bstride;   // see EdgeArgs
+    int* ns_edge; int* n_ns;
     int* deg; int* slice_tot; int* cta_flag;
     int* recv; int* send; int* row_ptr; int* n_edges; int* overflow; int max_nR; int zero_on_overflow;
 };
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(EW) void k_edge_count(EdgeDev a) {
         const bool is_tool = l.fl[i] & 2;
         if (!mine && !(a.cta == 1 && is_tool)) continue;   // wave-uniform
         int raw = 0, n;
-        if (a.topk_active) n = row_topk(a, l, i, thr, thr2, a.ell + ((long)b * a.N + i) * a.k, &raw);
+        if (a.topk_active) n = row_topk(a, l, i, thr, thr2, a.ell + (long)b * a.ell_bstride + (long)i * a.ell_stride, &raw);
         else n = row_radius_count(a, l, i, thr, thr2, 0, &raw);
         if (lane == 0) {
             if (mine) a.deg[(long)b * a.N + i] = n;        // senders not governed by the tool rule
@@ -365,11 +367,30 @@ __global__ __launch_bounds__(EW) void k_edge_count(EdgeDev a) {
     __syncthreads();
     // batch builder: all-or-nothing flag (graph.py:277); single-graph builder (cta == 2): unconditional (graph.py:119-122)
     const int flag = a.cta == 2 ? 1 : l.misc[0];
+    if (a.ell_full && a.cta && flag && ntool) {            // ascending tool index list for the slot-indexed rows
+        if (wave == 0) {
+            int m = 0;
+            for (int c = 0; c < (a.N + 63) >> 6; ++c) {
+                const int j = 64 * c + lane;
+                const bool t = j < a.N && (l.fl[j] & 2);
+                const unsigned long long bt = __ballot(t);
+                if (t) l.tlist[m + __popcll(bt & lanes_below(lane))] = (unsigned short)j;
+                m += __popcll(bt);
+            }
+        }
+        __syncthreads();
+    }
     // pass 2: add the all-or-nothing tool senders (graph.py:284,286) and total the slice
     int my = 0;
     for (int i = r0 + threadIdx.x; i < r1; i += EW) {
         int d = a.deg[(long)b * a.N + i];
-        if (a.cta && (l.fl[i] & 1) && flag && !(a.cta == 2 && (l.fl[i] & 2))) d += ntool;
+        if (a.cta && (l.fl[i] & 1) && flag && !(a.cta == 2 && (l.fl[i] & 2))) {
+            if (a.ell_full) {                               // slot-indexed graph: the tool senders follow the kept ones
+                int* row = a.ell + (long)b * a.ell_bstride + (long)i * a.ell_stride + d;
+                for (int m = 0; m < ntool; ++m) row[m] = l.tlist[m];
+            }
+            d += ntool;
+        }
         a.deg[(long)b * a.N + i] = d;
         my += d;
     }
@@ -460,7 +481,7 @@ __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
             const bool row_tools = tools_on && (l.fl[i] & 1) && !(a.cta == 2 && (l.fl[i] & 2));
             const int nt = row_tools ? ntool : 0;
             const int nk = d - nt;                          // kept senders from the ELL row
-            const int* ell = a.ell + ((long)b * a.N + i) * a.k;
+            const int* ell = a.ell + (long)b * a.ell_bstride + (long)i * a.ell_stride;
             for (int t = lane; t < nk; t += 64) {
                 const int j = ell[t];
                 const int p = off + t + (row_tools ? l.tprefix[j] : 0);
@@ -500,6 +521,52 @@ __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
     }
 }
 
+// ---- rollout fast path: index the slot-indexed graph left by k_edge_count (see EdgeArgs::ell_full).  One workgroup
+// per candidate: max_nR rule, receiver of every slot, list of the slots that are not self-loops (only those go
+// through the relation encoder), edge counts.  Integer scan, slot order = (receiver, position in row) = CSR order.
+__global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
+    __shared__ int scan[EW];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int total = 0;
+    for (int s = 0; s < a.slices; ++s) total += a.slice_tot[b * a.slices + s];
+    const bool hide = total > a.max_nR && a.zero_on_overflow;   // downstream kernels then see an empty graph
+    int* deg = a.deg + (long)b * a.N;
+    const int* ell = a.ell + (long)b * a.ell_bstride;
+    int* recv = a.recv + (long)b * a.edge_cap;
+    int* ns = a.ns_edge + (long)b * a.edge_cap;
+    const int per = (a.N + EW - 1) / EW;
+    const int i0 = min(a.N, tid * per), i1 = min(a.N, i0 + per);
+    int mine = 0;
+    for (int i = i0; i < i1; ++i) {
+        if (hide) deg[i] = 0;
+        const int d = deg[i];
+        for (int t = 0; t < d; ++t) mine += ell[(long)i * a.ell_stride + t] != i ? 1 : 0;
+    }
+    scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < EW; off <<= 1) {
+        int v = 0;
+        if (tid >= off) v = scan[tid - off];
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    int pos = scan[tid] - mine;
+    for (int i = i0; i < i1; ++i) {
+        const int d = deg[i];
+        for (int t = 0; t < d; ++t) {
+            const int e = i * a.ell_stride + t;
+            recv[e] = i;
+            if (ell[e] != i) ns[pos++] = e;
+        }
+    }
+    if (tid == EW - 1) {
+        a.n_ns[b] = scan[EW - 1];
+        a.n_edges[b] = hide ? 0 : total;
+        if (a.overflow && total > a.max_nR) atomicMax(a.overflow, total);
+    }
+}
+
 hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(void*, int, int), void* mark_ctx) {
     EdgeDev a;
     a.pos = h.pos; a.pos_bstride = h.pos_bstride; a.mask = h.mask; a.tool = h.tool; a.thr_vec = h.thr_vec; a.thr = h.thr;
@@ -507,6 +574,10 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     a.B = h.B; a.N = h.N; a.k = min(h.N, h.topk); a.topk_active = a.k < h.N; a.cta = h.cta; a.edge_cap = h.edge_cap;
     a.slices = h.slices; a.rows_per_slice = (h.N + h.slices - 1) / h.slices;
     a.ell = h.ell; a.deg = h.deg; a.slice_tot = h.slice_tot; a.cta_flag = h.cta_flag;
+    a.ell_full = h.ell_full && a.topk_active;
+    a.ell_stride = a.ell_full ? h.ell_stride : a.k;
+    a.ell_bstride = a.ell_full ? h.ell_bstride : (long)h.N * a.k;
+    a.ns_edge = h.ns_edge; a.n_ns = h.n_ns;
     a.recv = h.recv; a.send = h.send; a.row_ptr = h.row_ptr; a.n_edges = h.n_edges; a.overflow = h.overflow;
     a.max_nR = h.max_nR; a.zero_on_overflow = h.zero_on_overflow;
     const size_t lds = edge_lds_bytes(h.N);
@@ -524,7 +595,8 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     hipLaunchKernelGGL(k_edge_count, dim3(h.B * h.slices), dim3(EW), lds, st, a);
     if (mark) mark(mark_ctx, FAM_EDGE_COUNT, 1);
     if (mark) mark(mark_ctx, FAM_EDGE_EMIT, 0);
-    hipLaunchKernelGGL(k_edge_emit, dim3(h.B * h.slices), dim3(EW), lds, st, a);
+    if (a.ell_full) hipLaunchKernelGGL(k_ell_index, dim3(h.B), dim3(EW), 0, st, a);
+    else hipLaunchKernelGGL(k_edge_emit, dim3(h.B * h.slices), dim3(EW), lds, st, a);
     if (mark) mark(mark_ctx, FAM_EDGE_EMIT, 1);
     return hipGetLastError();
 }

@@ -17,7 +17,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int MP_WAVES = 4;
 struct MpDev {
     const float* C; const float* U; const float* V; float* agg;
-    const int* send; const int* row_ptr;
+    const int* send; const int* row_ptr; const int* deg; int ell_stride;   // ell_stride > 0: slot-indexed rows (GraphBufs)
     int B, N, edge_cap, c_cap;
     int cls; int N_o, M; const uint8_t* vmask;   // cls: U/V rows come from the class table (round 0 of a rollout)
     int dedupe; unsigned self_row;               // self-loop dedupe: C rows self_row / self_row+1 hold the object /
@@ -33,7 +33,8 @@ __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
     const long row = (long)blockIdx.x * MP_WAVES + (threadIdx.x >> 6);
     if (row >= (long)g.B * g.N) return;
     const int b = (int)(row / g.N), i = (int)(row - (long)b * g.N);
-    const int e0 = g.row_ptr[(long)b * (g.N + 1) + i], e1 = g.row_ptr[(long)b * (g.N + 1) + i + 1];
+    const int e0 = g.ell_stride ? i * g.ell_stride : g.row_ptr[(long)b * (g.N + 1) + i];
+    const int e1 = g.ell_stride ? e0 + g.deg[row] : g.row_ptr[(long)b * (g.N + 1) + i + 1];
     if (lane >= NFP / 4) return;
     // one scalar base per array + 32-bit element offsets (every buffer is < 2^32 floats): keeps the kernel at 64 VGPRs
     const float* __restrict__ C = g.C;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
 
 hipError_t launch_mp(const GraphBufs& g, int first_round, hipStream_t st) {
     const int cls = g.cls_on && first_round;
-    MpDev d{g.C, cls ? g.c_U : g.U, cls ? g.c_V : g.V, g.agg, g.send, g.row_ptr, g.B, g.N, g.edge_cap, g.c_cap,
+    MpDev d{g.C, cls ? g.c_U : g.U, cls ? g.c_V : g.V, g.agg, g.send, g.row_ptr, g.deg, g.ell_stride, g.B, g.N, g.edge_cap, g.c_cap,
             cls, g.N_o, g.M, g.vmask, g.c_self ? 1 : 0, (unsigned)g.self_row};
     const long rows = (long)g.B * g.N;
     const dim3 grid((unsigned)((rows + MP_WAVES - 1) / MP_WAVES));
