@@ -282,9 +282,10 @@ int pick_slices(int B, int N) {
 int auto_chunk(const ag_ctx* c, int B, int N) {
     if (c->chunk > 0) return std::min(c->chunk, B);
     if (const char* e = getenv("AG_CHUNK")) { int v = atoi(e); if (v > 0) return std::min(v, B); }
-    // Node chains run one 256-row workgroup per CU: pick the largest chunk whose workgroup count is <= 2 x 256 CUs,
-    // so the grid is two (nearly) full rounds and never spills a few workgroups into a third.
-    const long max_rows = 2L * 256 * 256;
+    // Node chains run 128-row workgroups, two per CU: the largest chunk whose workgroup count is <= 4 rounds of 512.
+    // (Measured on the 1024 x 2026 cloth batch: 64 candidates/launch 574 ms, 96: 564, 128: 559, 192: 561, 256: 558 -
+    // more rounds per launch dilute the lockstep store bursts and the launch tails; the workspace grows with it.)
+    const long max_rows = 4L * 256 * 256;
     long bc = max_rows / N;
     return (int)std::max(1L, std::min<long>(bc, B));
 }
@@ -619,6 +620,11 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     if (c->prof_mask) ns = 1;   // per-kernel event times are only meaningful without cross-stream interference
     int Bc = auto_chunk(c, p->B, N);
     if (ns > 1) Bc = std::min(Bc, (p->B + ns - 1) / ns);      // at least one chunk per stream
+    {   // equal-sized chunks, a multiple of the stream count of them (no short last chunk, no idle stream at the end)
+        int n_chunks = (p->B + Bc - 1) / Bc;
+        if (ns > 1) n_chunks = (n_chunks + ns - 1) / ns * ns;
+        Bc = (p->B + n_chunks - 1) / n_chunks;
+    }
     if (p->B <= 1) ns = 1;
     const int slices = pick_slices(Bc, N);
     const int ell = edge_ell_stride(N, p->topk);

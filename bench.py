@@ -287,6 +287,12 @@ def main():
         mp_bytes_launch = mp_bytes_round * (hi - lo) * H * R * 3 / max(1, n_mp // prof_steps)
         mp_avg_ms = ms_mp / max(1, n_mp)
         mp_gbs = mp_bytes_launch / (mp_avg_ms * 1e-3) / 1e9 if mp_avg_ms > 0 else 0.0
+        mp_traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_k_mp.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if n_mp and tj["candidates_per_launch"] == round((hi - lo) * H * R * 3 / max(1, n_mp // prof_steps)):
+                mp_traffic = tj["hbm_bytes_per_launch"]
         line = {
             "metric": "rollout-steps/sec", "value": total_steps * args.steps / dt, "unit": "rollout-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -304,10 +310,10 @@ def main():
                          "flop_per_edge": FLOP_PER_EDGE, "edges_per_launch": edges_per_launch},
             "roofline_hbm_kernel": {"bound": "hbm", "kernel": "k_mp", "achieved": mp_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": mp_gbs / PEAK_HBM_GBS, "avg_launch_ms": mp_avg_ms, "launches": int(n_mp),
-                                    "bytes_per_launch": mp_bytes_launch, "traffic": 859.2e6,
+                                    "bytes_per_launch": mp_bytes_launch, "traffic": mp_traffic,
                                     "note": "second-largest kernel family; achieved = compulsory HBM bytes / HIP-event "
                                             "time; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE per launch "
-                                            "(profiles/r01_pmc_summary.md): gathered V rows that miss L2 are the excess"},
+                                            "(profiles/r01_traffic_k_mp.json): gathered V rows that miss L2 are the excess"},
             "kernel_ms_per_rollout_single_stream": {f: v[0] / prof_steps for f, v in fam_ms.items()},
         }
         if dt_b3 is not None:
