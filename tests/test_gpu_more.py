@@ -495,3 +495,31 @@ def test_backoff_loop_vs_reference_golden(ag, dev):
     with pytest.raises(Exception, match="Exceeds max dims"):            # nothing left to shrink: the reference's loop dies the same way
         ag.construct_edges_with_backoff(*args, topk=1, max_nR=3, knn_thresh=0.1, min_kNN=0.2,
                                         max_y=np.float32(b["max_y"]), min_y=np.float32(b["min_y"]))
+
+
+def test_rollout_radius_only_graph(ag, O, dev):
+    """topk >= N: no top-k, the rollout takes the CSR (emit) path instead of the slot-indexed sender lists."""
+    rng = np.random.default_rng(21)
+    task = _task("rope", topk=500, adj_thresh=0.12, max_nR=20000)
+    W, m = _model(ag, O, "rope", 21, dev)
+    cloud = _rope(120, rng)
+    a = _actions(cloud, 3, 2, [2, 1, 3], rng)
+    out = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(a).to(dev), m, dev, _ppm(task, "rope"))
+    want = O.dynamics(W, 3, cloud, a, task)
+    assert np.abs(out["state_seqs"].cpu().numpy() - want["state_seqs"]).max() <= POS_TOL
+
+
+def test_rollout_at_the_particle_limit(ag, O, dev):
+    """4095 object particles + 1 tool = the edge builder's 4096-particle limit, one rollout step, against the oracle;
+    one particle more is refused loudly."""
+    rng = np.random.default_rng(22)
+    task = _task("cloth", max_nR=40000)
+    W, m = _model(ag, O, "cloth", 22, dev)
+    cloud = _grid(64, 0.3, 0.02, rng)[:4095]
+    a = _actions(cloud, 2, 1, 1, rng, spread=2.0)
+    out = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(a).to(dev), m, dev, _ppm(task, "cloth"))
+    want = O.dynamics(W, 3, cloud, a, task)
+    assert np.abs(out["state_seqs"].cpu().numpy() - want["state_seqs"]).max() <= POS_TOL
+    too_many = _grid(65, 0.3, 0.02, rng)[:4096]
+    with pytest.raises(NotImplementedError):
+        ag.dynamics(torch.from_numpy(too_many).to(dev), torch.from_numpy(a).to(dev), m, dev, _ppm(task, "cloth"))

@@ -106,6 +106,7 @@ def test_dense_dropin_matches_reference_layout(ag, dev):
     (1024, 5, 20, 0.40, False, 4),    # granular config-3 size
     (65, 1, 10, 0.5, False, 5),
     (1, 1, 10, 0.5, True, 6),         # degenerate: single object particle
+    (4094, 2, 10, 0.12, True, 7),     # the builder's maximum: 4096 particles (64 sender chunks)
 ])
 def test_edges_vs_oracle(ag, dev, N_o, M, topk, thr, cta, seed):
     from oracle import adaptigraph_oracle as O
