@@ -279,6 +279,14 @@ int pick_slices(int B, int N) {
     return std::max(1, std::min(s, 64));
 }
 
+// k_mp addresses C, U, V and agg with 32-bit element offsets: a launch chunk must keep every buffer below 2^32 floats
+int clamp_chunk_for_offsets(int Bc, int N, int c_cap) {
+    const long max_rows = ((1L << 32) / NFP) - 512;          // rows of NFP floats addressable with a 32-bit element offset
+    const long by_c = max_rows / std::max(1, c_cap);
+    const long by_n = max_rows / std::max(1, N);
+    return (int)std::max(1L, std::min<long>(Bc, std::min(by_c, by_n)));
+}
+
 int auto_chunk(const ag_ctx* c, int B, int N) {
     if (c->chunk > 0) return std::min(c->chunk, B);
     if (const char* e = getenv("AG_CHUNK")) { int v = atoi(e); if (v > 0) return std::min(v, B); }
@@ -552,8 +560,8 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     c->prof_stream = st;
-    const int Bc = auto_chunk(c, B, N);
     const int c_cap = (int)round_up(edge_cap, 256);
+    const int Bc = clamp_chunk_for_offsets(auto_chunk(c, B, N), N, c_cap);
     Work w{};
     int rc = ensure_slab(c, work_bytes(Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0));
     if (rc) return rc;
@@ -618,7 +626,7 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     int ns = std::max(1, std::min(c->n_streams, (int)ag_ctx::kMaxStreams));
     if (const char* e = getenv("AG_STREAMS")) ns = std::max(1, std::min(atoi(e), (int)ag_ctx::kMaxStreams));
     if (c->prof_mask) ns = 1;   // per-kernel event times are only meaningful without cross-stream interference
-    int Bc = auto_chunk(c, p->B, N);
+    int Bc = clamp_chunk_for_offsets(auto_chunk(c, p->B, N), N, edge_cap);
     if (ns > 1) Bc = std::min(Bc, (p->B + ns - 1) / ns);      // at least one chunk per stream
     {   // equal-sized chunks, a multiple of the stream count of them (no short last chunk, no idle stream at the end)
         int n_chunks = (p->B + Bc - 1) / Bc;
