@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel family (adds overhead)")
     ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-bf16x3", action="store_true", help="skip the secondary bf16x3-mode measurement")
+    ap.add_argument("--no-mpc-iter", action="store_true", help="skip the ms/MPC-iteration leg (profiling runs: its B=1 "
+                    "best-candidate rollouts would dilute per-kernel averages)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -241,18 +243,20 @@ def main():
     eval_fn = partial(ag.running_cost, error_func=err_fn, penalty_func=pen_fn, bbox=bbox, group=True if world > 1 else None)
     act0 = actions[0].to(dev)
     torch.manual_seed(1234)                                        # identical samples on every rank
-    ag.mpc_iteration(state0, act0, roll_fn, eval_fn, lo_lim, hi_lim, B, dev, group=True if world > 1 else None)
-    sync_all()
-    t0 = time.perf_counter()
-    n_mpc = 2
-    for _ in range(n_mpc):
-        mpc = ag.mpc_iteration(state0, act0, roll_fn, eval_fn, lo_lim, hi_lim, B, dev, group=True if world > 1 else None)
-    sync_all()
-    tm = torch.tensor([(time.perf_counter() - t0) / n_mpc], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-    ms_mpc = float(tm.item()) * 1e3
-    assert torch.isfinite(mpc["reward_seqs"]).all()
+    ms_mpc = None
+    if not args.no_mpc_iter:
+        ag.mpc_iteration(state0, act0, roll_fn, eval_fn, lo_lim, hi_lim, B, dev, group=True if world > 1 else None)
+        sync_all()
+        t0 = time.perf_counter()
+        n_mpc = 2
+        for _ in range(n_mpc):
+            mpc = ag.mpc_iteration(state0, act0, roll_fn, eval_fn, lo_lim, hi_lim, B, dev, group=True if world > 1 else None)
+        sync_all()
+        tm = torch.tensor([(time.perf_counter() - t0) / n_mpc], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ms_mpc = float(tm.item()) * 1e3
+        assert torch.isfinite(mpc["reward_seqs"]).all()
     ms_edge, n_edge = eng.kernel_stats("edge_enc") if fams else (0.0, 0)
     fam_ms = {f: eng.kernel_stats(f) for f in fams}
     if rank == 0:
