@@ -131,7 +131,7 @@ struct RollDev {
     float* node_in; float* feat12; float* group; int n_inst;
     float* c_node_in; int write_obj_cls;   // class-table inputs (GraphBufs): tool rows every init, object rows on demand
 };
-constexpr int RT = 256;
+constexpr int RT = 1024;
 
 // tool height: min object y (forward_dynamics.py:40,163) or masked mean (forward_dynamics.py:235,359).
 // `src` = (N_o,3) cloud of this candidate.  Result broadcast to the whole workgroup.
