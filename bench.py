@@ -320,6 +320,17 @@ def main():
                                             "(profiles/r01_traffic_k_mp.json): gathered V rows that miss L2 are the excess"},
             "kernel_ms_per_rollout_single_stream": {f: v[0] / prof_steps for f, v in fam_ms.items()},
         }
+        # whole-rollout arithmetic rate: FLOPs the kernels execute per rollout step and candidate
+        # (encoded edges x 140,100 + particles x (2 x 135,000 + 135,900) + 8 N^2 for the graph), and the reference
+        # formulation's F_ref = N*361,800 + N_o*90,900 + E*500,100 + 8 N^2 over the same time ("effective")
+        Np = N_o + 1
+        f_exec = E_enc * FLOP_PER_EDGE + Np * (2 * 135000 + 135900) + 8 * Np * Np
+        f_ref = Np * 361800 + N_o * 90900 + E * 500100 + 8 * Np * Np
+        t_step = dt / args.steps
+        line["end_to_end"] = {"executed_tflops": f_exec * total_steps / t_step / 1e12,
+                              "frac_of_fp32_mfma_peak": f_exec * total_steps / t_step / 1e12 / PEAK_FP32_MFMA_TFLOPS / world,
+                              "effective_reference_formulation_tflops": f_ref * total_steps / t_step / 1e12,
+                              "flop_per_step_executed": f_exec, "flop_per_step_reference_formulation": f_ref}
         if dt_b3 is not None:
             line["bf16x3_mode"] = {"value": total_steps * args.steps / dt_b3, "unit": "rollout-steps/s",
                                    "ms_per_step": dt_b3 / args.steps * 1e3, "dtype": "bf16x3 split, f32 accumulate",
