@@ -274,7 +274,11 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
 }
 
 int pick_slices(int B, int N) {
-    int s = (512 + B - 1) / B;     // ~512 sixteen-wave workgroups per launch
+    // one sixteen-wave workgroup per CU: every workgroup re-reads its candidate's positions and re-derives the chunk
+    // boxes, so fewer, longer row slices win (cloth, 128 candidates: 128 workgroups 56.8 ms per rollout, 256: 31.0,
+    // 384: 43.1, 512: 35.2, 1024: 41.9)
+    static const int target = getenv("AG_EDGE_WGS") ? atoi(getenv("AG_EDGE_WGS")) : 256;
+    int s = (target + B - 1) / B;
     s = std::min(s, std::max(1, N / 64));
     return std::max(1, std::min(s, 64));
 }
