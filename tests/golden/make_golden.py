@@ -226,7 +226,10 @@ def gen_masked_case(name, material, seed, refs):
     state_init = np.zeros((B, max_nobj, 3), np.float32)
     mask = np.zeros((B, max_nobj), bool)
     for b, c in enumerate(counts):
-        state_init[b, :c] = rope_cloud(c, rng)
+        if material == "rope":
+            state_init[b, :c] = rope_cloud(c, rng)
+        else:                                               # ragged prefix of a jittered grid (pitch per material)
+            state_init[b, :c] = grid_cloud(11, 0.12 if material == "granular" else 0.3, 0.02, rng)[:c]
         mask[b, :c] = True
     action = actions_near(state_init[0, :80], B, 1, rng, 2.2, 4.8)[:, 0]
     rec = Recorder(model)
@@ -427,8 +430,15 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more"} & set(sys.argv)):
     main()
+
+# dynamics_masked for the other two materials: gripper offset + connect_tools_all (cloth) and the 5-point pusher
+# (granular) in the masked / mean-height path (forward_dynamics.py:225-399)
+if __name__ == "__main__" and "--masked-more" in sys.argv:
+    _refs = import_reference()
+    gen_masked_case("dyn_masked_cloth", "cloth", 14, _refs)
+    gen_masked_case("dyn_masked_granular", "granular", 15, _refs)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -248,12 +248,14 @@ def test_dynamics_chunking_is_bit_invariant(ag, dev):
     assert torch.equal(part, ref[1:3])
 
 
-def test_dynamics_masked_vs_reference_golden(ag, dev):
-    g = load_golden("dyn_masked_rope")
+@pytest.mark.parametrize("name,material", [("dyn_masked_rope", "rope"), ("dyn_masked_cloth", "cloth"),
+                                           ("dyn_masked_granular", "granular")])
+def test_dynamics_masked_vs_reference_golden(ag, dev, name, material):
+    g = load_golden(name)
     task = task_of(g)
-    m = _model(ag, g, "rope", dev)
+    m = _model(ag, g, material, dev)
     out = ag.dynamics_masked(torch.from_numpy(g["state_init"]).to(dev), torch.from_numpy(g["state_mask"]).to(dev),
-                             torch.from_numpy(g["action"]).to(dev), m, dev, _ppm(task, "rope"))
+                             torch.from_numpy(g["action"]).to(dev), m, dev, _ppm(task, material))
     assert torch.equal(out["action_seqs"].cpu(), torch.from_numpy(g["action_seqs"]))
     err = np.abs(out["state_seqs"].cpu().numpy() - g["state_seqs"]).max()
     assert err <= POS_TOL, err

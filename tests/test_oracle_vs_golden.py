@@ -57,8 +57,9 @@ def test_dynamics_free_running(name):
     assert np.abs(out["state_seqs"] - g["state_seqs"]).max() < POS_TOL
 
 
-def test_dynamics_masked():
-    g = load_golden("dyn_masked_rope")
+@pytest.mark.parametrize("name", ["dyn_masked_rope", "dyn_masked_cloth", "dyn_masked_granular"])
+def test_dynamics_masked(name):
+    g = load_golden(name)
     W, task = O.weights_from_npz(g), task_of(g)
     out = O.dynamics_masked(W, int(g["pstep"]), g["state_init"], g["state_mask"], g["action"], task)
     assert np.array_equal(out["action_seqs"], g["action_seqs"])
