@@ -178,7 +178,7 @@ def task_scalars(task):
     return {k: task[k] for k in keep}
 
 
-def gen_dynamics_case(name, material, cloud, B, H, len_lo, len_hi, seed, refs, max_nR):
+def gen_dynamics_case(name, material, cloud, B, H, len_lo, len_hi, seed, refs, max_nR, lens=None, check_ties=True):
     DynamicsPredictor, _, dynamics, _ = refs
     rng = np.random.default_rng(seed)
     dyn, task = load_cfg(material)
@@ -187,7 +187,10 @@ def gen_dynamics_case(name, material, cloud, B, H, len_lo, len_hi, seed, refs, m
     model = make_model(DynamicsPredictor, dyn, seed)
     ppm = make_ppm(task, material)
     state = torch.from_numpy(cloud)
-    action = torch.from_numpy(actions_near(cloud, B, H, rng, len_lo, len_hi))
+    action = actions_near(cloud, B, H, rng, len_lo, len_hi)
+    if lens is not None:
+        action[..., 3] = np.asarray(lens, np.float32)
+    action = torch.from_numpy(action)
     rec = Recorder(model)
     np.random.seed(seed)
     out = quiet(dynamics, state, action, model, torch.device("cpu"), ppm)
@@ -196,7 +199,7 @@ def gen_dynamics_case(name, material, cloud, B, H, len_lo, len_hi, seed, refs, m
     mask = torch.ones((B, N), dtype=torch.bool)
     tool = torch.zeros((B, N), dtype=torch.bool)
     tool[:, cloud.shape[0]:] = True
-    for st in rec.steps:
+    for st in rec.steps if check_ties else []:
         assert_no_topk_boundary_tie(torch.from_numpy(st["state_last"]), mask, tool, task["adj_thresh"], task["topk"])
     store = weights_npz(model)
     store["state0"] = cloud
@@ -437,6 +440,12 @@ if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "-
 # (granular) in the masked / mean-height path (forward_dynamics.py:225-399)
 if __name__ == "__main__" and "--masked-more" in sys.argv:
     _refs = import_reference()
+    # action_repeat == 0 (push length < 1): that candidate's slot stays zero and the NEXT look-ahead step starts from
+    # the zero cloud (forward_dynamics.py:32,38) - all particles coincide there, so every top-k choice is a tie and only
+    # the final states are compared
+    gen_dynamics_case("dyn_rope_repeat0", "rope", rope_cloud(120, np.random.default_rng(16)), B=3, H=2, len_lo=1.1,
+                      len_hi=1.9, seed=16, refs=_refs, max_nR=4000, lens=[[0.5, 2.5], [3.5, 0.5], [1.5, 4.5]],
+                      check_ties=False)
     gen_masked_case("dyn_masked_cloth", "cloth", 14, _refs)
     gen_masked_case("dyn_masked_granular", "granular", 15, _refs)
 

@@ -303,3 +303,15 @@ def test_dynamics_vs_oracle_free_running_20_steps(ag, dev):
     out = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(action).to(dev), m, dev, _ppm(task, "granular"))
     err = np.abs(out["state_seqs"].cpu().numpy() - want["state_seqs"]).max()
     assert err <= POS_TOL, err
+
+
+def test_dynamics_repeat_zero_vs_reference_golden(ag, dev):
+    """action_repeat == 0 (forward_dynamics.py:32,38) against the reference's own output."""
+    g = load_golden("dyn_rope_repeat0")
+    task = task_of(g)
+    m = _model(ag, g, "rope", dev)
+    out = ag.dynamics(torch.from_numpy(g["state0"]).to(dev), torch.from_numpy(g["action"]).to(dev), m, dev, _ppm(task, "rope"))
+    got = out["state_seqs"].cpu().numpy()
+    assert np.all(got[0, 0] == 0) and np.all(got[1, 1] == 0)
+    assert torch.equal(out["action_seqs"].cpu(), torch.from_numpy(g["action_seqs"]))
+    assert np.abs(got - g["state_seqs"]).max() <= POS_TOL

@@ -168,3 +168,14 @@ def test_backoff_loop_vs_reference():
     assert trail == b["trail"]
     (wr, ws), = split_edges(g, "backoff::")
     assert np.array_equal(r, wr) and np.array_equal(s, ws)
+
+
+def test_dynamics_repeat_zero_vs_reference():
+    """forward_dynamics.py:32,38: action_repeat == 0 leaves that slot zero and the next look-ahead step starts from the
+    zero cloud (every top-k choice there is a tie between coincident particles: only the states are compared)."""
+    g = load_golden("dyn_rope_repeat0")
+    W, task = O.weights_from_npz(g), task_of(g)
+    out = O.dynamics(W, int(g["pstep"]), g["state0"], g["action"], task)
+    assert np.array_equal(out["action_seqs"], g["action_seqs"])
+    assert np.all(g["state_seqs"][0, 0] == 0) and np.all(g["state_seqs"][1, 1] == 0)
+    assert np.abs(out["state_seqs"] - g["state_seqs"]).max() < POS_TOL
