@@ -97,10 +97,13 @@ class Engine:
     def set_chunk(self, n):
         self.check(self.lib.ag_ctx_set_chunk(self._ctx, int(n)))
 
-    def set_profiling(self, families):
+    def set_profiling(self, families, keep_streams=False):
+        """HIP-event timing of the listed kernel families.  Pins the rollout to one stream unless keep_streams."""
         mask = 0
         for f in families:
             mask |= 1 << _lib.KERNEL_FAMILIES.index(f)
+        if keep_streams and mask:
+            mask |= 1 << 30
         self.check(self.lib.ag_ctx_set_profiling(self._ctx, mask))
 
     def kernel_stats(self, family):

@@ -631,7 +631,9 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     if ((long)p->B * N < 65536) ns = 1;   // small batches are dispatch-bound: a second stream only doubles the launches
                                           // (rope 64 x 301: 10.8 ms on one stream, 12.9 ms on two)
     if (const char* e = getenv("AG_STREAMS")) ns = std::max(1, std::min(atoi(e), (int)ag_ctx::kMaxStreams));
-    if (c->prof_mask) ns = 1;   // per-kernel event times are only meaningful without cross-stream interference
+    // per-kernel event times are only meaningful without cross-stream interference; bit 30 of the mask keeps the
+    // streams (the durations then include whatever the other stream ran beside the kernel)
+    if ((c->prof_mask & 0x3fffffffu) && !(c->prof_mask & (1u << 30))) ns = 1;
     int Bc = clamp_chunk_for_offsets(auto_chunk(c, p->B, N), N, edge_cap);
     if (ns > 1) Bc = std::min(Bc, (p->B + ns - 1) / ns);      // at least one chunk per stream
     {   // equal-sized chunks, a multiple of the stream count of them (no short last chunk, no idle stream at the end)

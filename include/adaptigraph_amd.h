@@ -192,7 +192,9 @@ int ag_cost_penalty(ag_ctx* ctx, void* stream, const float* d_state_pred, const 
 
 /* Introspection for bench.py / tests: HIP-event time of every launch of a kernel family, recorded on the stream the
  * kernels run on.  family_mask bit i enables family i of: edge_count, edge_emit, prep, node_enc, edge_enc, mp,
- * node_prop, node_final, roll_init, roll_update (0 = off, -1 = all).  ag_ctx_kernel_stats waits for the recorded
+ * node_prop, node_final, roll_init, roll_update (0 = off).  A non-zero mask pins the rollout to ONE stream so that a
+ * duration measures the kernel alone; bit 30 keeps the streams instead (durations then include the other stream's
+ * co-running kernels - what a kernel trace of a normal run shows).  ag_ctx_kernel_stats waits for the recorded
  * events and returns the total milliseconds and launch count since the last reset. */
 int ag_ctx_set_profiling(ag_ctx* ctx, int32_t family_mask);
 int ag_ctx_kernel_stats(ag_ctx* ctx, const char* kernel, double* out_total_ms, int64_t* out_launches);
