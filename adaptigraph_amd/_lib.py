@@ -26,7 +26,7 @@ EXPORTS = ["ag_abi_version", "ag_ctx_create", "ag_ctx_destroy", "ag_last_error",
            "ag_ctx_set_chunk", "ag_build_edges", "ag_forward", "ag_rollout", "ag_rollout_async",
            "ag_ctx_set_profiling", "ag_ctx_kernel_stats", "ag_ctx_reset_stats",
            "ag_cost_chamfer", "ag_cost_state_stats", "ag_cost_penalty", "ag_ctx_set_precision", "ag_build_edges_single",
-           "ag_edges_apply_tool_rule"]
+           "ag_edges_apply_tool_rule", "ag_mppi_sample", "ag_mppi_update", "ag_mppi_clip"]
 
 
 class AgDims(C.Structure):
@@ -73,6 +73,9 @@ def load():
     lib.ag_cost_chamfer.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.ag_cost_state_stats.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.ag_cost_penalty.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]
+    lib.ag_mppi_sample.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]
+    lib.ag_mppi_update.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp]
+    lib.ag_mppi_clip.argtypes = [vp, vp, vp, vp, vp, C.c_int64, vp]
     lib.ag_ctx_set_profiling.argtypes = [vp, i32]
     lib.ag_ctx_kernel_stats.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.ag_ctx_reset_stats.argtypes = [vp]

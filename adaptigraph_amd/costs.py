@@ -17,7 +17,9 @@ def running_cost(state, action, state_cur, error_func, penalty_func, bbox, group
     bsz, n_look_forward = state.shape[0], state.shape[1]
     state_flat = state.reshape(bsz * n_look_forward, state.shape[2], state.shape[3])
     error = error_func(state_flat).reshape(bsz, n_look_forward)                        # :35-36
-    error_weight = 2.0 / (_global_max(error, group) + 1e-6)                            # :37
+    # :37 forms 2.0 / (error.max().item() + 1e-6) in Python double precision and rounds to fp32 only when it scales the
+    # error; the same arithmetic on a float64 device scalar needs no host sync
+    error_weight = (2.0 / (_global_max(error, group).to(torch.float64) + 1e-6)).to(torch.float32)
     collision_penalty = penalty_func(state, action, state_cur)                         # :39
     st = state_stats(state_flat).reshape(bsz, n_look_forward, 5)                       # :41-44 in one pass
     xmin, xmax, zmin, zmax = st[..., 1], st[..., 2], st[..., 3], st[..., 4]

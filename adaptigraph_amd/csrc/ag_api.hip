@@ -567,10 +567,15 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
     const int c_cap = (int)round_up(edge_cap, 256);
     const int Bc = clamp_chunk_for_offsets(auto_chunk(c, B, N), N, c_cap);
     Work w{};
-    int rc = ensure_slab(c, work_bytes(Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0));
+    int rc = ensure_slab(c, work_bytes(Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0) + (size_t)B * 4 + 512);
     if (rc) return rc;
     rc = carve_work(c, w, Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0);
     if (rc) return rc;
+    // the caller's graphs may be overflowed (true count > edge_cap, indices never written): guard, then report
+    int* n_eff = c->slab.take<int>((size_t)B);
+    if (c->slab.used > c->slab.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
+    HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, st));
+    HIPCHK(c, launch_edge_guard(d_n_edges, B, edge_cap, n_eff, c->d_overflow, st));
     for (int b0 = 0; b0 < B; b0 += Bc) {
         const int nb = std::min(Bc, B - b0);
         GraphBufs g = w.g;
@@ -578,13 +583,17 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
         g.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
         g.group = const_cast<float*>(d_group) + (size_t)b0 * N * n_inst;
         g.recv = d_recv + (size_t)b0 * edge_cap; g.send = d_send + (size_t)b0 * edge_cap;
-        g.row_ptr = d_row_ptr + (size_t)b0 * (N + 1); g.n_edges = d_n_edges + b0;
+        g.row_ptr = d_row_ptr + (size_t)b0 * (N + 1); g.n_edges = n_eff + b0; g.n_guard = n_eff + b0;
         { Scoped p(c, FAM_PREP);
           HIPCHK(c, launch_prep(d_state + (size_t)b0 * N_HIS * N * 3, d_attrs + (size_t)b0 * N * 2,
                                 d_action + (size_t)b0 * N * 3, d_phys + (size_t)b0 * N, g, st)); }
         rc = run_model(c, g, d_pred_pos + (size_t)b0 * n_p * 3, d_pred_motion + (size_t)b0 * n_p * 3, st);
         if (rc) return rc;
     }
+    int seen = 0;
+    HIPCHK(c, hipMemcpyAsync(&seen, c->d_overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (seen > 0) return fail(c, AG_ERR_MAX_NR, "Exceeds max dims: a graph had %d edges, edge_cap=%d", seen, edge_cap);
     return AG_OK;
 }
 
@@ -666,9 +675,15 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         }
     }
 
+    // AG_TEST_FAIL_AT_CHUNK=n (test hook): fail with AG_ERR_HIP before enqueuing chunk n, as a failed launch would
+    const int fail_at = getenv("AG_TEST_FAIL_AT_CHUNK") ? atoi(getenv("AG_TEST_FAIL_AT_CHUNK")) : -1;
+    // The chunk loop as a callable: whatever it returns, the forked streams are joined back into the caller's stream
+    // below, so that a failure in the middle never leaves work of this call in flight on a stream the caller cannot see.
+    auto enqueue_chunks = [&]() -> int {
     bool obj_cls_ready[ag_ctx::kMaxStreams] = {false, false, false, false};   // per workspace, per call
     int ci = 0;
     for (int b0 = 0; b0 < p->B; b0 += Bc, ++ci) {
+        if (ci == fail_at) return fail(c, AG_ERR_HIP, "test hook: injected failure before chunk %d", ci);
         const int nb = std::min(Bc, p->B - b0);
         Work& w = ws[ci % ns];
         hipStream_t cs = streams[ci % ns];
@@ -722,12 +737,18 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
             }
         }
     }
-    for (int i = 1; i < ns; ++i) {
-        HIPCHK(c, hipEventRecord(c->ev_join[i], c->aux_stream[i]));
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[i], 0));
+    return AG_OK;
+    };
+    const int rc_loop = enqueue_chunks();
+    int rc_join = AG_OK;
+    for (int i = 1; i < ns; ++i) {                           // join on EVERY exit once the fork has happened
+        hipError_t e = hipEventRecord(c->ev_join[i], c->aux_stream[i]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_join[i], 0);
+        if (e != hipSuccess && rc_join == AG_OK && rc_loop == AG_OK)
+            rc_join = fail(c, AG_ERR_HIP, "joining stream %d failed: %s", i, hipGetErrorString(e));
     }
     c->prof_stream = st;
-    return AG_OK;
+    return rc_loop ? rc_loop : rc_join;
 }
 
 int ag_rollout(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0, const uint8_t* d_obj_mask,
@@ -781,6 +802,34 @@ int ag_cost_penalty(ag_ctx* c, void* stream, const float* d_state_pred, const fl
     c->prof_stream = static_cast<hipStream_t>(stream);
     Scoped p(c, FAM_COST);
     HIPCHK(c, launch_penalty(d_state_pred, d_action, d_state_init, B, H, N, kind, ratio, d_out, static_cast<hipStream_t>(stream)));
+    return AG_OK;
+}
+
+int ag_mppi_sample(ag_ctx* c, void* stream, const float* d_act_seq, const float* d_lo, const float* d_hi, const float* d_rnd,
+                   const float* d_scale, int32_t S, int32_t H, int32_t mode, float push_length, float* d_out) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_lo || !d_hi || !d_rnd || !d_out || S < 1 || H < 1 || (mode != 0 && mode != 1) || (mode == 1 && (!d_act_seq || !d_scale)))
+        return fail(c, AG_ERR_INVALID, "ag_mppi_sample: bad arguments S=%d H=%d mode=%d", S, H, mode);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, launch_mppi_sample(d_act_seq, d_lo, d_hi, d_rnd, d_scale, S, H, mode, push_length, d_out, static_cast<hipStream_t>(stream)));
+    return AG_OK;
+}
+
+int ag_mppi_update(ag_ctx* c, void* stream, const float* d_act_seqs, const float* d_reward, const float* d_lo,
+                   const float* d_hi, int32_t B, int32_t H, float reward_weight, float push_length, float* d_out) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_act_seqs || !d_reward || !d_lo || !d_hi || !d_out || B < 1 || H < 1)
+        return fail(c, AG_ERR_INVALID, "ag_mppi_update: bad arguments B=%d H=%d", B, H);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, launch_mppi_update(d_act_seqs, d_reward, d_lo, d_hi, B, H, reward_weight, push_length, d_out, static_cast<hipStream_t>(stream)));
+    return AG_OK;
+}
+
+int ag_mppi_clip(ag_ctx* c, void* stream, const float* d_in, const float* d_lo, const float* d_hi, int64_t n, float* d_out) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_in || !d_lo || !d_hi || !d_out || n < 1) return fail(c, AG_ERR_INVALID, "ag_mppi_clip: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, launch_mppi_clip(d_in, d_lo, d_hi, d_out, (long)n, static_cast<hipStream_t>(stream)));
     return AG_OK;
 }
 

@@ -132,6 +132,7 @@ struct GraphBufs {
     long self_row;                         // row of C where c_self[0..1] were copied (k_mp reads them from there)
     const int* ns_edge; const int* n_ns;   // (B,edge_cap), (B,) or null
     const float* wb3;                      // bf16x3 weight image: non-null selects the bf16x3 chains (ag_mlp.hip)
+    const int* n_guard;                    // ag_forward: guarded per-candidate edge counts (k_edge_guard), else null
 };
 constexpr int B3_PHASE_BYTES = 2 * 5 * 3 * 64 * 16;   // 30,720
 constexpr int B3_PHASES = 58;
@@ -145,6 +146,7 @@ hipError_t launch_node_prop(const float* wblob, const GraphBufs& g, int first_ro
 hipError_t launch_node_final(const float* wblob, const GraphBufs& g, int first_round, float clamp, float* pred_pos,
                              float* pred_motion, hipStream_t st);
 
+hipError_t launch_edge_guard(const int* n_edges, int B, int edge_cap, int* n_eff, int* overflow, hipStream_t st);
 // model-input preparation for ag_forward: state (B,n_his,N,3) etc. -> node_in, feat12
 hipError_t launch_prep(const float* state, const float* attrs, const float* action, const float* phys,
                        const GraphBufs& g, hipStream_t st);
@@ -174,6 +176,13 @@ hipError_t launch_state_stats(const float* state, int R, int N, const float* box
 hipError_t launch_penalty(const float* state_pred, const float* action, const float* state_init, int B, int H, int N,
                           int kind, float ratio, float* out, hipStream_t st);
 size_t chamfer_max_points();
+
+// MPPI sampling / update (ag_mppi.hip)
+hipError_t launch_mppi_sample(const float* act_seq, const float* lo, const float* hi, const float* rnd,
+                              const float* scale, int S, int H, int mode, float pl, float* out, hipStream_t st);
+hipError_t launch_mppi_update(const float* acts, const float* reward, const float* lo, const float* hi, int B, int H,
+                              float rw, float pl, float* out, hipStream_t st);
+hipError_t launch_mppi_clip(const float* in, const float* lo, const float* hi, float* out, long n, hipStream_t st);
 
 hipError_t launch_roll_init(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);
 hipError_t launch_roll_update(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);

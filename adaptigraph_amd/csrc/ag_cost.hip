@@ -200,12 +200,14 @@ hipError_t launch_chamfer(const float* x, const float* y, const uint8_t* xm, con
                           int By, float* out, hipStream_t st) {
     ChamferDev a{x, y, xm, ym, out, R, N, M, By};
     const size_t lds = (size_t)(3 * N + 3 * M) * 4;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr_devices = 0;              // per-device function attribute (see ag_edges.hip)
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess) dev_id = 0;
+    if (dev_id >= 64 || !(attr_devices >> dev_id & 1ull)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chamfer),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         if (e != hipSuccess) return e;
-        attr = true;
+        if (dev_id < 64) attr_devices |= 1ull << dev_id;
     }
     hipLaunchKernelGGL(k_chamfer, dim3(R), dim3(CT), lds, st, a);
     return hipGetLastError();

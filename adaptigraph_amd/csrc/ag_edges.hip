@@ -581,15 +581,18 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     a.recv = h.recv; a.send = h.send; a.row_ptr = h.row_ptr; a.n_edges = h.n_edges; a.overflow = h.overflow;
     a.max_nR = h.max_nR; a.zero_on_overflow = h.zero_on_overflow;
     const size_t lds = edge_lds_bytes(h.N);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the > 64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: track it per device ordinal
+    static unsigned long long attr_devices = 0;
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess) dev_id = 0;
+    if (dev_id >= 64 || !(attr_devices >> dev_id & 1ull)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_count),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_emit), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 256);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev_id < 64) attr_devices |= 1ull << dev_id;
     }
     if (mark) mark(mark_ctx, FAM_EDGE_COUNT, 0);
     hipLaunchKernelGGL(k_edge_count, dim3(h.B * h.slices), dim3(EW), lds, st, a);

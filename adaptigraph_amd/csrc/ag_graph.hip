@@ -22,6 +22,7 @@ struct MpDev {
     int cls; int N_o, M; const uint8_t* vmask;   // cls: U/V rows come from the class table (round 0 of a rollout)
     int dedupe; unsigned self_row;               // self-loop dedupe: C rows self_row / self_row+1 hold the object /
                                                  // tool self-loop constants (appended to the C buffer)
+    const int* n_guard;                          // ag_forward: guarded edge counts (0 = treat the graph as empty), or null
 };
 // Class-table rows (round 0 of a rollout): a particle that takes part in an edge is valid by construction (masked
 // pairs never pass the radius test, graph.py:253-256), so its row is a pure function of its index; a receiver
@@ -34,7 +35,8 @@ __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
     if (row >= (long)g.B * g.N) return;
     const int b = (int)(row / g.N), i = (int)(row - (long)b * g.N);
     const int e0 = g.ell_stride ? i * g.ell_stride : g.row_ptr[(long)b * (g.N + 1) + i];
-    const int e1 = g.ell_stride ? e0 + g.deg[row] : g.row_ptr[(long)b * (g.N + 1) + i + 1];
+    int e1 = g.ell_stride ? e0 + g.deg[row] : g.row_ptr[(long)b * (g.N + 1) + i + 1];
+    if (g.n_guard && g.n_guard[b] == 0) e1 = e0;             // overflowed caller graph: row_ptr is not to be trusted
     if (lane >= NFP / 4) return;
     // one scalar base per array + 32-bit element offsets (every buffer is < 2^32 floats): keeps the kernel at 64 VGPRs
     const float* __restrict__ C = g.C;
@@ -80,11 +82,28 @@ __global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
 hipError_t launch_mp(const GraphBufs& g, int first_round, hipStream_t st) {
     const int cls = g.cls_on && first_round;
     MpDev d{g.C, cls ? g.c_U : g.U, cls ? g.c_V : g.V, g.agg, g.send, g.row_ptr, g.deg, g.ell_stride, g.B, g.N, g.edge_cap, g.c_cap,
-            cls, g.N_o, g.M, g.vmask, g.c_self ? 1 : 0, (unsigned)g.self_row};
+            cls, g.N_o, g.M, g.vmask, g.c_self ? 1 : 0, (unsigned)g.self_row, g.n_guard};
     const long rows = (long)g.B * g.N;
     const dim3 grid((unsigned)((rows + MP_WAVES - 1) / MP_WAVES));
     if (cls) hipLaunchKernelGGL(k_mp<true>, grid, dim3(MP_WAVES * 64), 0, st, d);
     else hipLaunchKernelGGL(k_mp<false>, grid, dim3(MP_WAVES * 64), 0, st, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ caller-graph guard
+// ag_forward consumes edge lists the CALLER built.  ag_build_edges reports the TRUE edge count even when it exceeds the
+// caller's edge_cap and then writes no indices (pad_torch semantics, src/dynamics/utils.py:54-56): such a graph must not
+// be walked.  n_eff[b] = n_edges[b] if it fits, else 0 (the kernels then see an empty graph) and *overflow = max count.
+__global__ void k_edge_guard(const int* __restrict__ n_edges, int B, int edge_cap, int* __restrict__ n_eff, int* overflow) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int n = n_edges[b];
+    const bool bad = n > edge_cap || n < 0;
+    n_eff[b] = bad ? 0 : n;
+    if (bad) atomicMax(overflow, n < 0 ? 0x7fffffff : n);
+}
+hipError_t launch_edge_guard(const int* n_edges, int B, int edge_cap, int* n_eff, int* overflow, hipStream_t st) {
+    hipLaunchKernelGGL(k_edge_guard, dim3((B + 255) / 256), dim3(256), 0, st, n_edges, B, edge_cap, n_eff, overflow);
     return hipGetLastError();
 }
 

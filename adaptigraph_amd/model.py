@@ -58,8 +58,9 @@ class DynamicsPredictor(nn.Module):
         if unsupported or input_dim != 6 or rel_input_dim != 17 or self.n_his != 4 or \
                 not (self.nf_particle == self.nf_relation == self.nf_effect == 150):
             raise NotImplementedError(
-                "the HIP engine implements the configuration of every shipped dynamics yaml: input_dim 6, "
-                f"rel_input_dim 17, n_his 4, nf 150 (got {input_dim}, {rel_input_dim}, {self.n_his}, {self.nf_effect})")
+                "the HIP kernels are built for input_dim 6, rel_input_dim 17, n_his 4, nf 150 - the configuration of "
+                "config/dynamics/{rope,granular,cloth}.yaml; softbody.yaml (n_his 5, rel_input_dim 20) is not "
+                f"implemented (got {input_dim}, {rel_input_dim}, {self.n_his}, {self.nf_effect})")
         self.input_dim, self.rel_input_dim = input_dim, rel_input_dim
 
         nf = self.nf_effect

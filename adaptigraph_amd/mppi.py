@@ -1,72 +1,96 @@
-"""MPPI sampling / update with the reference's names and arithmetic (src/planning/plan_utils.py:31-101) and one whole
-MPC iteration (src/planning/real_world/planner.py:234-277) wired to the HIP engine.
+"""MPPI sampling / update on the HIP engine, behind the reference's function names (src/planning/plan_utils.py:31-101),
+and one whole MPC iteration (src/planning/real_world/planner.py:234-277).
 
-The sampling and the softmax-weighted update are O(B*H*4) elementwise work on torch tensors; the op order is the
-reference's, so with the same torch generator state on the same device the results are bit-identical to it.
-What the engine changes is upstream: the reference evaluates n_sample = 20000 in 40 host-side chunks of 500
+The arithmetic lives in csrc/ag_mppi.hip (ag_mppi_sample / ag_mppi_update / ag_mppi_clip).  This module only draws
+the random numbers - with the same torch calls, shapes and order as the reference, so a caller that seeds torch gets
+the reference's draws - and hands device pointers to the C-ABI.  There is no CPU path.
+
+What the engine changes upstream: the reference evaluates n_sample = 20000 in 40 host-side chunks of 500
 (plan.py:177-182, 241-247) because its dense rollout does not fit; here one call takes the whole batch (the engine
 chunks on the device), optionally sharded over the ranks of a torch.distributed group.
 """
 from __future__ import annotations
 
-import math
-
 import torch
-import torch.nn.functional as F
+
+from .context import default_engine, ptr, current_stream, _require_gpu
 
 
-def angle_normalize(x):
-    return ((x + math.pi) % (2 * math.pi)) - math.pi                                  # plan_utils.py:31-32
+def _dev_f32(t, dev):
+    return torch.as_tensor(t).detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+def _limits(lo, hi, dev):
+    lo, hi = _dev_f32(lo, dev).reshape(-1), _dev_f32(hi, dev).reshape(-1)
+    assert lo.numel() == 4 and hi.numel() == 4
+    return lo, hi
 
 
 def clip_actions(action, action_lower_lim, action_upper_lim):
-    action_new = action.clone()                                                        # plan_utils.py:35-39
-    action_new[..., 2] = angle_normalize(action[..., 2])
-    action_new.data.clamp_(action_lower_lim, action_upper_lim)
-    return action_new
+    """plan_utils.py:35-39: theta wrapped into [-pi, pi) (angle_normalize, :31-32), every component clamped."""
+    dev = _require_gpu(action.device)
+    eng = default_engine(dev)
+    assert action.shape[-1] == 4
+    a = _dev_f32(action, dev)
+    lo, hi = _limits(action_lower_lim, action_upper_lim, dev)
+    out = torch.empty_like(a)
+    if a.numel():
+        eng.check(eng.lib.ag_mppi_clip(eng.ctx, current_stream(dev), ptr(a), ptr(lo), ptr(hi), a.numel() // 4, ptr(out)))
+    return out
+
+
+def angle_normalize(x):
+    """plan_utils.py:31-32 on a tensor of angles (any shape)."""
+    dev = _require_gpu(x.device)
+    a = torch.zeros(x.shape + (4,), device=dev, dtype=torch.float32)
+    a[..., 2] = x
+    inf = torch.full((4,), float("inf"), device=dev)
+    return clip_actions(a, -inf, inf)[..., 2]
 
 
 def sample_action_seq(act_seq, action_lower_lim, action_upper_lim, n_sample, device, iter_index=0, noise_level=0.3,
-                      push_length=0.10):
-    """plan_utils.py:42-77 -> (n_sample, n_look_ahead, 4)"""
-    if iter_index == 0:                                                                # resample completely
-        return torch.rand((n_sample, act_seq.shape[0], act_seq.shape[1]), device=device) * \
-            (action_upper_lim - action_lower_lim) + action_lower_lim
-    n_look_ahead = act_seq.shape[0]
+                      push_length=0.10, _draws=None):
+    """plan_utils.py:42-77 -> (n_sample, n_look_ahead, 4).  iter_index 0: uniform resampling inside the limits; else
+    Gaussian perturbation of the nominal push's start / end points (sample 0 keeps the nominal action).
+    `_draws`: the random numbers to use instead of drawing them (tests: the reference's recorded draws)."""
+    dev = _require_gpu(device)
+    eng = default_engine(dev)
+    H = act_seq.shape[0]
     assert act_seq.shape[-1] == 4
-    act_seqs = torch.stack([act_seq.clone()] * n_sample)
-    xs, ys, thetas, lengths = act_seqs[:, :, 0], act_seqs[:, :, 1], act_seqs[:, :, 2], act_seqs[:, :, 3]
-    x_ends = xs - lengths * push_length * torch.cos(thetas)
-    y_ends = ys - lengths * push_length * torch.sin(thetas)
-    for i in range(n_look_ahead):
-        noise_sample = torch.normal(0, noise_level, (n_sample, 4), device=device)
-        act_residual = (0.1 * (10 ** i)) * noise_sample
-        xs_i = xs[:, i] + act_residual[:, 0]
-        ys_i = ys[:, i] + act_residual[:, 1]
-        x_ends_i = x_ends[:, i] + act_residual[:, 2]
-        y_ends_i = y_ends[:, i] + act_residual[:, 3]
-        thetas_i = torch.atan2(ys_i - y_ends_i, xs_i - x_ends_i)
-        lengths_i = torch.norm(torch.stack([x_ends_i - xs_i, y_ends_i - ys_i], dim=-1), dim=-1).clone() / push_length
-        act_seq_i = clip_actions(torch.stack([xs_i, ys_i, thetas_i, lengths_i], dim=-1), action_lower_lim, action_upper_lim)
-        act_seqs[1:, i] = act_seq_i[1:].clone()                                        # sample 0 keeps the nominal action
-    return act_seqs
+    lo, hi = _limits(action_lower_lim, action_upper_lim, dev)
+    out = torch.empty((n_sample, H, 4), device=dev, dtype=torch.float32)
+    if iter_index == 0:
+        u = torch.rand((n_sample, H, 4), device=dev) if _draws is None else _dev_f32(_draws, dev)     # :49
+        assert u.shape == (n_sample, H, 4)
+        eng.check(eng.lib.ag_mppi_sample(eng.ctx, current_stream(dev), None, ptr(lo), ptr(hi), ptr(u), None, n_sample, H,
+                                         0, float(push_length), ptr(out)))
+        return out
+    if _draws is None:                                                                             # :60, one draw per step
+        noise = torch.stack([torch.normal(0, noise_level, (n_sample, 4), device=dev) for _ in range(H)])
+    else:
+        noise = _dev_f32(_draws, dev)
+    assert noise.shape == (H, n_sample, 4)
+    scale = torch.tensor([0.1 * (10 ** i) for i in range(H)], dtype=torch.float32).to(dev)          # :62
+    nominal = _dev_f32(act_seq, dev)
+    eng.check(eng.lib.ag_mppi_sample(eng.ctx, current_stream(dev), ptr(nominal), ptr(lo), ptr(hi), ptr(noise), ptr(scale),
+                                     n_sample, H, 1, float(push_length), ptr(out)))
+    return out
 
 
 def optimize_action_mppi(act_seqs, reward_seqs, reward_weight=100.0, action_lower_lim=None, action_upper_lim=None,
                          push_length=0.10):
-    """plan_utils.py:80-101: softmax-weighted average of start and end points, re-encoded as (x, y, theta, length)."""
-    weight_seqs = F.softmax(reward_seqs * reward_weight, dim=0).unsqueeze(-1)
-    assert act_seqs.shape[-1] == 4
-    xs, ys, thetas, lengths = act_seqs[:, :, 0], act_seqs[:, :, 1], act_seqs[:, :, 2], act_seqs[:, :, 3]
-    x_ends = xs - lengths * push_length * torch.cos(thetas)
-    y_ends = ys - lengths * push_length * torch.sin(thetas)
-    x = torch.sum(weight_seqs * xs, dim=0)
-    y = torch.sum(weight_seqs * ys, dim=0)
-    x_end = torch.sum(weight_seqs * x_ends, dim=0)
-    y_end = torch.sum(weight_seqs * y_ends, dim=0)
-    theta = torch.atan2(y - y_end, x - x_end)
-    length = torch.norm(torch.stack([x_end - x, y_end - y], dim=-1), dim=-1) / push_length
-    return clip_actions(torch.stack([x, y, theta, length], dim=-1), action_lower_lim, action_upper_lim)
+    """plan_utils.py:80-101: softmax(reward * reward_weight)-weighted mean of the candidates' start and end points,
+    re-encoded as (x, z, theta, length) and limited -> (n_look_ahead, 4)."""
+    dev = _require_gpu(act_seqs.device)
+    eng = default_engine(dev)
+    B, H = act_seqs.shape[0], act_seqs.shape[1]
+    assert act_seqs.shape[-1] == 4 and reward_seqs.shape == (B,)
+    acts, rew = _dev_f32(act_seqs, dev), _dev_f32(reward_seqs, dev)
+    lo, hi = _limits(action_lower_lim, action_upper_lim, dev)
+    out = torch.empty((H, 4), device=dev, dtype=torch.float32)
+    eng.check(eng.lib.ag_mppi_update(eng.ctx, current_stream(dev), ptr(acts), ptr(rew), ptr(lo), ptr(hi), B, H,
+                                     float(reward_weight), float(push_length), ptr(out)))
+    return out
 
 
 @torch.no_grad()

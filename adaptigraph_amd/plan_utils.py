@@ -1,14 +1,18 @@
-"""decode_action with the reference's exact arithmetic (src/planning/plan_utils.py:11-20)."""
+"""Action codec of the planner: replaces decode_action (reference src/planning/plan_utils.py:11-20).
+
+An action is (x, z, theta, length): a push that starts at (x, z), heads AGAINST the direction theta for `push_length`
+per repeat, and is applied int(length) times.  The decode runs with torch ops on the action's own device (the
+reference decodes there too, forward_dynamics.py:23), each product and difference in the reference's order so the
+fp32 bits agree: end = start - push_length * (cos theta, sin theta).
+"""
 import torch
 
 
 def decode_action(action, push_length=0.10):
-    x_start = action[:, :, 0]
-    z_start = action[:, :, 1]
-    theta = action[:, :, 2]
-    length = action[:, :, 3].detach()
-    action_repeat = length.to(torch.int32)
-    x_end = x_start - push_length * torch.cos(theta)
-    z_end = z_start - push_length * torch.sin(theta)
-    decoded_action = torch.stack([x_start, z_start, x_end, z_end], dim=-1)
-    return decoded_action, action_repeat
+    """action (..., 4) -> decoded (..., 4) = [x_start, z_start, x_end, z_end], action_repeat (...,) int32 (truncation)."""
+    start = action[..., 0:2]
+    heading = action[..., 2]
+    reach = push_length * torch.stack((torch.cos(heading), torch.sin(heading)), dim=-1)
+    decoded = torch.cat((start, start - reach), dim=-1)
+    repeat = action[..., 3].detach().to(torch.int32)
+    return decoded, repeat

@@ -84,26 +84,30 @@ def make_actions(B, H, repeat, cloud, rng):
     return a
 
 
-def cpu_baseline(cloud, task, W, seconds=12.0):
-    """The numpy oracle (CPU restatement of the reference, oracle/) on a bounded sample of the same workload."""
-    from oracle import adaptigraph_oracle as O
-    rng = np.random.default_rng(1)
-    act = make_actions(1, 1, 2, cloud, rng)
-    t0 = time.time()
-    steps = 0
-    while True:
-        O.dynamics(W, 3, cloud, act, task)
-        steps += 2
-        if time.time() - t0 > seconds:
-            break
-    dt = time.time() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:  # noqa: BLE001
-        cores = os.cpu_count() or 1
-    return {"value": steps / dt, "unit": "rollout-steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"numpy oracle, cloth 2025+1 particles, 1 candidate x {steps} rollout steps in {dt:.1f}s"}
+def cpu_baseline(cloud, task, W, actions, picks, gpu_seqs, tol=1e-5):
+    """CPU leg (after the timed region; the only place the oracle is used): the numpy oracle (CPU restatement of the
+    reference, oracle/) rolls out `picks` - candidates OF THE TIMED BATCH - one per worker process and BLAS thread, in
+    a child process (this one holds the GPU and must not fork).  Returns (cpu_baseline, parity_check): the timing of
+    that bounded sample and the comparison of its results with what the GPU produced for the same candidates in the
+    last timed step."""
+    import subprocess
+    import tempfile
+    workers = max(1, min(len(picks), 16, os.cpu_count() or 1))      # a one-GPU box has a 16-core CPU share
+    with tempfile.TemporaryDirectory() as td:
+        src, dst = os.path.join(td, "in.npz"), os.path.join(td, "out.npz")
+        np.savez(src, cloud=cloud, actions=actions[picks], pstep=3,
+                 task_json=np.frombuffer(json.dumps(task).encode(), dtype=np.uint8),
+                 **{"w::" + k: v for k, v in W.items()})
+        subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", src, dst, str(workers)], check=True, cwd=ROOT)
+        z = np.load(dst)
+        want, dt, steps = z["state_seqs"], float(z["seconds"]), int(z["steps"])
+    err = float(np.abs(gpu_seqs - want).max())
+    base = {"value": steps / dt, "unit": "rollout-steps/s", "cores": workers, "kind": "port",
+            "sample": f"numpy oracle, {len(picks)} candidates of the timed batch x {steps // len(picks)} rollout steps "
+                      f"(cloth 2025+1 particles), one candidate per process and BLAS thread, {dt:.1f}s wall"}
+    parity = {"candidates": [int(p) for p in picks], "max_abs_err": err, "tol": tol, "ok": bool(err <= tol),
+              "what": "state_seqs of these candidates from the LAST TIMED step vs the oracle (free-running, all steps)"}
+    return base, parity
 
 
 def main():
@@ -172,9 +176,12 @@ def main():
         eng.set_chunk(args.chunk)
     flag = torch.zeros(64, dtype=torch.int32, device=dev)
 
+    last = {}
+
     def one_step():
         out = ag.dynamics(state0, a_local, model, dev, ppm, _sync=False, _overflow_flag=flag)
         seq = out["state_seqs"]                                        # (b, H, N_o, 3)
+        last["seq"] = seq                                              # a reference, not a copy (parity_check below)
         # running_cost (plan.py:27-59): the two batch-global maxima are all-reduced (MAX) when the batch is sharded
         rew = ag.running_cost(seq, a_local, state0, error_func=err_fn, penalty_func=pen_fn, bbox=bbox,
                               group=True if world > 1 else None)["reward_seqs"]
@@ -198,6 +205,11 @@ def main():
     dt = time.perf_counter() - t0
     assert int(flag[0].item()) <= task["max_nR"], "a graph exceeded max_nR during the bench"
     assert torch.isfinite(costs).all()
+    # candidates of the timed batch that the CPU leg re-computes with the oracle: first, last and evenly spaced ones
+    # (every launch chunk of both streams is hit); their GPU results come from the LAST TIMED step
+    n_pick = 0 if args.no_cpu_baseline or world > 1 else max(2, min(16, os.cpu_count() or 2, hi - lo))
+    picks = sorted({int(round(i * (hi - lo - 1) / max(1, n_pick - 1))) for i in range(n_pick)})
+    timed_seqs = last["seq"][picks].cpu().numpy() if picks else None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -351,8 +363,10 @@ def main():
                                    "ms_per_step": dt_b3 / args.steps * 1e3, "dtype": "bf16x3 split, f32 accumulate",
                                    "note": "opt-in ag_ctx_set_precision(1); same 1e-5 parity bar; not the headline"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cloud, task, Wt)
+            line["cpu_baseline"], line["parity_check"] = cpu_baseline(cloud, task, Wt, actions.numpy(), picks, timed_seqs)
         print(json.dumps(line))
+        if "parity_check" in line and not line["parity_check"]["ok"]:
+            sys.exit("bench: the timed rollout differs from the oracle by more than 1e-5")
     if world > 1:
         dist.destroy_process_group()
 

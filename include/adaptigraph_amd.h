@@ -40,7 +40,7 @@ extern "C" {
 #define AG_ERR_UNSUPPORTED -4  /* configuration outside what the kernels implement                            */
 #define AG_ERR_NO_WEIGHTS -5   /* forward/rollout before ag_ctx_load_weights                                   */
 
-#define AG_ABI_VERSION 3
+#define AG_ABI_VERSION 4
 #define AG_NUM_WEIGHT_TENSORS 22
 
 typedef struct ag_ctx ag_ctx;
@@ -140,7 +140,10 @@ int ag_edges_apply_tool_rule(ag_ctx* ctx, void* stream, const float* d_pos, cons
  *   d_state (B,n_his,N,3); d_attrs (B,N,2); d_action (B,N,3); d_phys (B,N) physics parameter per particle, zero
  *   for the trailing N-n_p tool particles (model.py:206-207); d_group (B,N,n_inst) = [p_instance ; 0] (model.py:264);
  *   edges as produced by ag_build_edges (must be sorted by receiver; row_ptr consistent).
- * Outputs d_pred_pos, d_pred_motion (B,n_p,3) (model.py:335-338). */
+ * Outputs d_pred_pos, d_pred_motion (B,n_p,3) (model.py:335-338).
+ * A graph whose d_n_edges[b] exceeds edge_cap (ag_build_edges reports the true count and writes no indices then) is
+ * never walked: the call returns AG_ERR_MAX_NR - the reference raises Exception("Exceeds max dims") at the pad_torch in
+ * front of its forward (utils.py:63-65).  Synchronises the stream once at the end to read that flag. */
 int ag_forward(ag_ctx* ctx, void* stream, const float* d_state, const float* d_attrs, const float* d_action,
                const float* d_phys, const float* d_group, int32_t n_inst, const int32_t* d_recv, const int32_t* d_send,
                const int32_t* d_row_ptr, const int32_t* d_n_edges, int32_t edge_cap, int32_t B, int32_t N, int32_t n_p,
@@ -189,6 +192,29 @@ int ag_cost_state_stats(ag_ctx* ctx, void* stream, const float* d_state, int32_t
 int ag_cost_penalty(ag_ctx* ctx, void* stream, const float* d_state_pred, const float* d_action,
                     const float* d_state_init, int32_t B, int32_t H, int32_t N, int32_t kind, float sim_real_ratio,
                     float* d_out);
+
+/* ---- MPPI sampling / update: SURVEY §8(f) rank 2 (reference src/planning/plan_utils.py:31-101) ---- */
+
+/* sample_action_seq (plan_utils.py:42-77).  d_act_seq (H,4) nominal actions [x, z, theta, length]; d_lo, d_hi (4,)
+ * action limits; d_out (S,H,4).
+ *   mode 0 (iter_index == 0, :48-50): d_rnd (S,H,4) uniform [0,1) draws -> d_out = u*(hi-lo)+lo; d_act_seq, d_scale unused.
+ *   mode 1 (:51-77): d_rnd (H,S,4) = for look-ahead step i the (S,4) draws of N(0, noise_level) in the reference's draw
+ *     order; d_scale (H,) = fp32(0.1 * 10^i) (:62); start and end point of the nominal push are perturbed, re-encoded
+ *     as (theta, length) and limited (:31-39); sample 0 keeps the nominal action (:75).
+ * The random draws are an input so that the function is testable against the reference's vectors. */
+int ag_mppi_sample(ag_ctx* ctx, void* stream, const float* d_act_seq, const float* d_lo, const float* d_hi,
+                   const float* d_rnd, const float* d_scale, int32_t S, int32_t H, int32_t mode, float push_length,
+                   float* d_out);
+
+/* optimize_action_mppi (plan_utils.py:80-101): softmax(reward * reward_weight) over the B candidates, weighted mean of
+ * the start and end points per look-ahead step, re-encoded and limited.  d_act_seqs (B,H,4), d_reward (B,), d_out (H,4).
+ * One workgroup per look-ahead step, fixed-order reductions (deterministic). */
+int ag_mppi_update(ag_ctx* ctx, void* stream, const float* d_act_seqs, const float* d_reward, const float* d_lo,
+                   const float* d_hi, int32_t B, int32_t H, float reward_weight, float push_length, float* d_out);
+
+/* clip_actions (plan_utils.py:35-39) on n actions: theta wrapped into [-pi, pi), every component clamped. */
+int ag_mppi_clip(ag_ctx* ctx, void* stream, const float* d_in, const float* d_lo, const float* d_hi, int64_t n,
+                 float* d_out);
 
 /* Introspection for bench.py / tests: HIP-event time of every launch of a kernel family, recorded on the stream the
  * kernels run on.  family_mask bit i enables family i of: edge_count, edge_emit, prep, node_enc, edge_enc, mp,

@@ -583,6 +583,13 @@ def gen_mppi_case(name):
     torch.manual_seed(8)
     s1 = PU.sample_action_seq(act_seq, lo, hi, 64, torch.device("cpu"), iter_index=1, noise_level=0.3, push_length=0.1)
     store["sample_iter0"], store["sample_iter1"] = s0.numpy(), s1.numpy()
+    # the random draws behind those two samples (same seeds, same torch calls in the same order as plan_utils.py:49,60),
+    # so that a sampler which takes its draws as an input can be checked against the reference's outputs
+    torch.manual_seed(7)
+    store["uniform_iter0"] = torch.rand((64, 3, 4)).numpy()
+    torch.manual_seed(8)
+    store["noise_iter1"] = torch.stack([torch.normal(0, 0.3, (64, 4)) for _ in range(3)]).numpy()
+    assert np.array_equal((torch.from_numpy(store["uniform_iter0"]) * (hi - lo) + lo).numpy(), store["sample_iter0"])
     torch.manual_seed(9)
     rewards = torch.randn(64) * 0.02 - 5.0
     store["rewards"] = rewards.numpy()

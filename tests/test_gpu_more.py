@@ -541,3 +541,49 @@ def test_repeated_calls_are_bit_identical_across_workspace_recarves(ag, O, dev):
         ref = out.clone() if ref is None else ref
         assert torch.equal(out, ref), it
         ag.dynamics(s0, a[: 5 + 7 * it], m, dev, _ppm(task, "cloth"))   # another shape in between
+
+
+def test_forward_on_overflowed_edgelist_raises_instead_of_faulting(ag, O, dev):
+    """An EdgeList built with a too-small edge_cap carries the TRUE edge count and unwritten index arrays
+    (pad_torch semantics); forward() must refuse it like the reference's pad_torch does (utils.py:63-65)."""
+    rng = np.random.default_rng(2)
+    cloud = _grid(12, 0.1, 0.01, rng)
+    N = cloud.shape[0]
+    _, m = _model(ag, O, "rope", 2, dev)
+    st = torch.from_numpy(np.repeat(cloud[None, None], 4, 1)).to(dev)   # (1, 4, N, 3)
+    ones = torch.ones((1, N), dtype=torch.bool, device=dev)
+    args = dict(state=st, attrs=torch.cat([torch.ones(1, N, 1), torch.zeros(1, N, 1)], -1).to(dev),
+                p_instance=torch.ones((1, N - 1, 1), device=dev), action=torch.zeros((1, N, 3), device=dev),
+                rope_physics_param=torch.full((1, 1), 0.5, device=dev))
+    small = ag.construct_edges_index(st[:, -1], 0.5, ones, ~ones, 10, False, edge_cap=100)
+    small.recv.fill_(2 ** 30)                                           # what torch.empty may hold: wild indices
+    small.send.fill_(2 ** 30)
+    with pytest.raises(Exception, match="Exceeds max dims"):
+        m(edges=small, **args)
+    ok = ag.construct_edges_index(st[:, -1], 0.5, ones, ~ones, 10, False)
+    pos, _ = m(edges=ok, **args)                                        # the ctx is still usable
+    assert torch.isfinite(pos).all()
+
+
+def test_failed_rollout_joins_its_streams_and_leaves_the_ctx_usable(ag, O, dev):
+    """A failure in the middle of the chunk loop (after the fork onto the second stream) must join the streams back;
+    the next rollout on the same ctx equals a fresh ctx's bit for bit."""
+    import os
+    rng = np.random.default_rng(29)
+    task = _task("cloth")
+    W, m = _model(ag, O, "cloth", 29, dev)
+    cloud = _grid(40, 0.3, 0.02, rng)                                   # 96 x 1601 rows: two streams
+    a = torch.from_numpy(_actions(cloud, 96, 1, 2, rng, spread=2.0)).to(dev)
+    s0 = torch.from_numpy(cloud).to(dev)
+    good = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"].clone()
+    os.environ["AG_TEST_FAIL_AT_CHUNK"] = "1"
+    try:
+        with pytest.raises(RuntimeError, match="injected failure"):
+            ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))
+    finally:
+        del os.environ["AG_TEST_FAIL_AT_CHUNK"]
+    torch.cuda.synchronize()                                            # nothing of the failed call is left in flight
+    again = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"]
+    assert torch.equal(again, good)
+    _, fresh = _model(ag, O, "cloth", 29, dev)
+    assert torch.equal(ag.dynamics(s0, a, fresh, dev, _ppm(task, "cloth"))["state_seqs"], good)
