@@ -94,6 +94,31 @@ def construct_edges_single(pos, thr, mask, tool_mask, topk, connect_tools_all, c
     return recv.astype(np.int32), send.astype(np.int32)
 
 
+def selection_margin(pos, thr, mask, tool_mask, topk):
+    """How far (in fp32 squared-distance units) the positions are from changing the graph of construct_edges_single:
+    the smallest of (a) |dis - thr^2| over unmasked, non tool-tool pairs (a pair entering / leaving the radius) and
+    (b) d_(k+1) - d_(k) over receiver rows whose k-th and (k+1)-th nearest senders are both inside the radius (two
+    senders swapping places at the top-k boundary).  A position perturbation e moves dis by about 2*sqrt(dis)*2e, so a
+    margin below ~4*thr*tol means the reference's own edge choice is not determined to within a position tolerance tol:
+    free-running comparisons past such a step are comparisons of two different, equally valid graphs."""
+    N = pos.shape[0]
+    thr2 = F32(F32(thr) * F32(thr))
+    dis = pairwise_dis(pos)
+    mask = np.asarray(mask, bool)
+    tool = np.asarray(tool_mask, bool)
+    dead = ~(mask[:, None] & mask[None, :]) | (tool[:, None] & tool[None, :])
+    radius = np.abs(np.where(dead, np.inf, dis) - thr2).min() if (~dead).any() else np.inf
+    swap = np.inf
+    k = min(N, int(topk))
+    if k < N:
+        d = np.where(dead, BIG, dis)
+        part = np.partition(d, (k - 1, k), axis=1)
+        both_in = part[:, k] < thr2
+        if both_in.any():
+            swap = (part[both_in, k] - part[both_in, k - 1]).min()
+    return float(min(radius, swap))
+
+
 def _flat_smallest(values, k):
     """torch.topk(values, k, largest=False) membership on a flat vector; ties resolved (value, index) lexicographic
     (torch's own choice is implementation-defined; fixtures hold no such tie)."""
