@@ -220,7 +220,7 @@ size_t work_bytes(int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices
                   bool own_group, int N_o, int ell_stride) {
     const size_t rows = (size_t)Bc * N;
     size_t bytes = 16 * 256;
-    bytes += rows * (NODE_IN + F12 + (own_group ? n_inst : 0)) * 4 + 5 * rows * NFP * 4 + ((size_t)Bc * c_cap + 256) * NFP * 4;
+    bytes += rows * (NODE_IN + F12 + (own_group ? n_inst : 0)) * 4 + 6 * rows * NFP * 4 + ((size_t)Bc * c_cap + 256) * NFP * 4;
     if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 3) * 4 + 3 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
     if (roll) bytes += (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
                        (size_t)cls_rows(N_o, N - N_o, Bc) * (NODE_IN + 4 * NFP) * 4;
@@ -237,9 +237,8 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
     w.g.group = own_group ? s.take<float>(rows * n_inst) : nullptr;
     w.g.eff = s.take<float>(rows * NFP);
     w.g.P = s.take<float>(rows * NFP);
-    w.g.U = s.take<float>(rows * NFP);
-    w.g.V = s.take<float>(rows * NFP);
-    w.g.agg = s.take<float>(rows * NFP);
+    for (int par = 0; par < 2; ++par)
+        for (int k = 0; k < 2; ++k) w.g.UV[par][k] = s.take<float>(rows * NFP);
     w.g.C = s.take<float>(((size_t)Bc * c_cap + 256) * NFP);   // + room for the two self-loop constant rows
     w.g.B = Bc; w.g.N = N; w.g.n_inst = n_inst; w.g.edge_cap = edge_cap; w.g.c_cap = c_cap; w.g.n_p = N_o;
     if (own_edges) {
@@ -283,7 +282,7 @@ int pick_slices(int B, int N) {
     return std::max(1, std::min(s, 64));
 }
 
-// k_mp addresses C, U, V and agg with 32-bit element offsets: a launch chunk must keep every buffer below 2^32 floats
+// the gather (ag_mlp.hip: gather_agg) addresses C, U and V with 32-bit element offsets: a launch chunk must keep every buffer below 2^32 floats
 int clamp_chunk_for_offsets(int Bc, int N, int c_cap) {
     const long max_rows = ((1L << 32) / NFP) - 512;          // rows of NFP floats addressable with a 32-bit element offset
     const long by_c = max_rows / std::max(1, c_cap);
@@ -308,9 +307,8 @@ int run_model(ag_ctx* c, const GraphBufs& g, float* pred_pos, float* pred_motion
     if (!g.cls_on) { Scoped p(c, FAM_NODE_ENC); HIPCHK(c, launch_node_enc(c->d_w, g, 0, (long)g.B * g.N, st)); }
     { Scoped p(c, FAM_EDGE_ENC); HIPCHK(c, launch_edge_enc(c->d_w, g, st)); }
     for (int ps = 0; ps < c->dims.pstep; ++ps) {
-        { Scoped p(c, FAM_MP); HIPCHK(c, launch_mp(g, ps == 0, st)); }
-        if (ps + 1 < c->dims.pstep) { Scoped p(c, FAM_NODE_PROP); HIPCHK(c, launch_node_prop(c->d_w, g, ps == 0, st)); }
-        else { Scoped p(c, FAM_NODE_FINAL); HIPCHK(c, launch_node_final(c->d_w, g, ps == 0, c->dims.motion_clamp, pred_pos, pred_motion, st)); }
+        if (ps + 1 < c->dims.pstep) { Scoped p(c, FAM_NODE_PROP); HIPCHK(c, launch_node_prop(c->d_w, g, ps, st)); }
+        else { Scoped p(c, FAM_NODE_FINAL); HIPCHK(c, launch_node_final(c->d_w, g, ps, c->dims.motion_clamp, pred_pos, pred_motion, st)); }
     }
     return AG_OK;
 }

@@ -107,7 +107,10 @@ struct GraphBufs {
     float* feat12;    // (B*N, F12)      [res0, res1, res2, cur] (model.py:156-166)
     float* group;     // (B*N, n_inst)   [p_instance ; 0]        (model.py:264)
     float* eff;       // particle effect, updated in place by the propagate chain
-    float* P; float* U; float* V; float* agg;
+    float* P;
+    float* UV[2][2];  // [parity][0 = U, 1 = V]: message-passing round r reads parity (r-1)&1 and writes parity r&1 (the gather
+                      // is fused into the chain that rewrites U/V, so a launch must not read what it writes); k_node_enc
+                      // writes parity 1, which round 0 reads
     float* C;         // (B*c_cap, NFP)  W1*rel_enc + b_rp
     const int* recv; const int* send; const int* row_ptr; const int* n_edges;
     const int* deg; int ell_stride;   // ell_stride > 0: slot-indexed graph of the rollout fast path (row i owns slots
@@ -140,10 +143,9 @@ inline long cls_rows(int N_o, int M, int B) { return 2L * N_o + (long)B * M; }
 // row0/nrows select a slice of the class table when g.cls_on, else all B*N rows are encoded
 hipError_t launch_node_enc(const float* wblob, const GraphBufs& g, long row0, long nrows, hipStream_t st);
 hipError_t launch_edge_enc(const float* wblob, const GraphBufs& g, hipStream_t st);
-// first_round: U/V/eff of the round come from the class table (when g.cls_on)
-hipError_t launch_mp(const GraphBufs& g, int first_round, hipStream_t st);
-hipError_t launch_node_prop(const float* wblob, const GraphBufs& g, int first_round, hipStream_t st);
-hipError_t launch_node_final(const float* wblob, const GraphBufs& g, int first_round, float clamp, float* pred_pos,
+// message-passing round `round` (gather fused into the chain); round 0: U/V/eff come from the class table (when g.cls_on)
+hipError_t launch_node_prop(const float* wblob, const GraphBufs& g, int round, hipStream_t st);
+hipError_t launch_node_final(const float* wblob, const GraphBufs& g, int round, float clamp, float* pred_pos,
                              float* pred_motion, hipStream_t st);
 
 hipError_t launch_edge_guard(const int* n_edges, int B, int edge_cap, int* n_eff, int* overflow, hipStream_t st);

@@ -1,94 +1,11 @@
-// HBM/L2-bound kernels of the rollout step: edge->node message passing with a CSR segmented sum, model-input
-// preparation, and the per-step rollout bookkeeping (tool keypoints, history shift, capture).  gfx950 only.
+// Small HBM-bound kernels of the rollout step: model-input preparation, the guard for caller-built graphs and the per-step
+// rollout bookkeeping (tool keypoints, history shift, capture).  gfx950 only.  (The edge->node message passing lives in
+// ag_mlp.hip, fused into the propagate chains: gather_agg.)
 #include "ag_common.h"
 
 namespace ag {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------------------------------------------ message passing
-// agg[i] = sum over edges e with recv(e) = i of ReLU(C[e] + U[i] + V[send(e)])
-//   = Rr^T.bmm(relation_propagator([rel_enc | eff_r | eff_s]))           (reference model.py:312-324)
-// with W_rp factored as [W1|W2|W3]: C = W1*rel_enc + b, U = W2*eff, V = W3*eff.
-// One wavefront per receiver.  Edges are CSR-sorted by receiver, so the segment is contiguous; lanes map to
-// FEATURES (40 lanes x float4 = one 640-B row), so every C / V row is one coalesced read and the segmented sum
-// needs no cross-lane traffic and no atomics: each lane adds its 4 features edge after edge, in edge order.
-// Roofline: HBM/L2 bytes.  Algorithmic bytes per receiver: deg*(640 C + 640 V + 4 idx) + 640 U + 640 agg.
-constexpr int MP_WAVES = 4;
-struct MpDev {
-    const float* C; const float* U; const float* V; float* agg;
-    const int* send; const int* row_ptr; const int* deg; int ell_stride;   // ell_stride > 0: slot-indexed rows (GraphBufs)
-    int B, N, edge_cap, c_cap;
-    int cls; int N_o, M; const uint8_t* vmask;   // cls: U/V rows come from the class table (round 0 of a rollout)
-    int dedupe; unsigned self_row;               // self-loop dedupe: C rows self_row / self_row+1 hold the object /
-                                                 // tool self-loop constants (appended to the C buffer)
-    const int* n_guard;                          // ag_forward: guarded edge counts (0 = treat the graph as empty), or null
-};
-// Class-table rows (round 0 of a rollout): a particle that takes part in an edge is valid by construction (masked
-// pairs never pass the radius test, graph.py:253-256), so its row is a pure function of its index; a receiver
-// without edges gets agg = 0 whatever its U row is.
-// <= 64 VGPRs (8 waves/SIMD bound) so that one k_mp wavefront fits on a SIMD beside two MLP-chain wavefronts
-template <bool CLS>
-__global__ __launch_bounds__(MP_WAVES * 64, 8) void k_mp(MpDev g) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * MP_WAVES + (threadIdx.x >> 6);
-    if (row >= (long)g.B * g.N) return;
-    const int b = (int)(row / g.N), i = (int)(row - (long)b * g.N);
-    const int e0 = g.ell_stride ? i * g.ell_stride : g.row_ptr[(long)b * (g.N + 1) + i];
-    int e1 = g.ell_stride ? e0 + g.deg[row] : g.row_ptr[(long)b * (g.N + 1) + i + 1];
-    if (g.n_guard && g.n_guard[b] == 0) e1 = e0;             // overflowed caller graph: row_ptr is not to be trusted
-    if (lane >= NFP / 4) return;
-    // one scalar base per array + 32-bit element offsets (every buffer is < 2^32 floats): keeps the kernel at 64 VGPRs
-    const float* __restrict__ C = g.C;
-    const float* __restrict__ V = g.V;
-    const unsigned l4 = 4u * lane;
-    const unsigned cb = (unsigned)b * (unsigned)g.c_cap;
-    const unsigned vb = CLS ? 0u : (unsigned)b * (unsigned)g.N;
-    const unsigned tool_row0 = 2u * g.N_o + (unsigned)b * g.M - g.N_o;        // + sender index (>= N_o) = class row
-    const unsigned self_row = g.self_row + (i >= g.N_o ? 1u : 0u);            // C row of this receiver's self-loop
-    const unsigned urow = CLS ? (i >= g.N_o ? tool_row0 + i : (unsigned)i) : (unsigned)row;
-    const f32x4 u = *reinterpret_cast<const f32x4*>(g.U + urow * (unsigned)NFP + l4);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int* snd = g.send + (long)b * g.edge_cap;
-    int e = e0;
-    constexpr int UNR = 4;
-    for (; e + UNR <= e1; e += UNR) {                        // 2*UNR independent 16-B loads in flight per lane
-        f32x4 c[UNR], v[UNR];
-#pragma unroll
-        for (int k = 0; k < UNR; ++k) {
-            const int sj = snd[e + k];
-            const unsigned crow = (g.dedupe && sj == i) ? self_row : cb + (unsigned)(e + k);
-            const unsigned vrow = CLS ? (sj >= g.N_o ? tool_row0 + sj : (unsigned)sj) : vb + (unsigned)sj;
-            c[k] = *reinterpret_cast<const f32x4*>(C + crow * (unsigned)NFP + l4);
-            v[k] = *reinterpret_cast<const f32x4*>(V + vrow * (unsigned)NFP + l4);
-        }
-#pragma unroll
-        for (int k = 0; k < UNR; ++k)
-#pragma unroll
-            for (int d = 0; d < 4; ++d) acc[d] += fmaxf((c[k][d] + u[d]) + v[k][d], 0.0f);
-    }
-    for (; e < e1; ++e) {
-        const int sj = snd[e];
-        const unsigned crow = (g.dedupe && sj == i) ? self_row : cb + (unsigned)e;
-        const unsigned vrow = CLS ? (sj >= g.N_o ? tool_row0 + sj : (unsigned)sj) : vb + (unsigned)sj;
-        const f32x4 c = *reinterpret_cast<const f32x4*>(C + crow * (unsigned)NFP + l4);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(V + vrow * (unsigned)NFP + l4);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) acc[d] += fmaxf((c[d] + u[d]) + v[d], 0.0f);
-    }
-    *reinterpret_cast<f32x4*>(g.agg + (unsigned)row * (unsigned)NFP + l4) = acc;
-}
-
-hipError_t launch_mp(const GraphBufs& g, int first_round, hipStream_t st) {
-    const int cls = g.cls_on && first_round;
-    MpDev d{g.C, cls ? g.c_U : g.U, cls ? g.c_V : g.V, g.agg, g.send, g.row_ptr, g.deg, g.ell_stride, g.B, g.N, g.edge_cap, g.c_cap,
-            cls, g.N_o, g.M, g.vmask, g.c_self ? 1 : 0, (unsigned)g.self_row, g.n_guard};
-    const long rows = (long)g.B * g.N;
-    const dim3 grid((unsigned)((rows + MP_WAVES - 1) / MP_WAVES));
-    if (cls) hipLaunchKernelGGL(k_mp<true>, grid, dim3(MP_WAVES * 64), 0, st, d);
-    else hipLaunchKernelGGL(k_mp<false>, grid, dim3(MP_WAVES * 64), 0, st, d);
-    return hipGetLastError();
-}
 
 // ------------------------------------------------------------------------------------------------ caller-graph guard
 // ag_forward consumes edge lists the CALLER built.  ag_build_edges reports the TRUE edge count even when it exceeds the

@@ -25,6 +25,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <vector>
 
 namespace ag {
 
@@ -37,6 +39,20 @@ constexpr int QCH = 5;                      // chunks (of 4 k-steps) per staged 
 constexpr int BUF_FLOATS = QCH * CHUNK_FLOATS_MB5;   // one LDS staging buffer (25,600 B)
 constexpr int Q_FLOATS = BUF_FLOATS;        // quarters 0..2
 constexpr int Q3_FLOATS = (KCH - 3 * QCH) * CHUNK_FLOATS_MB5;
+// Per-wavefront LDS staging area behind the two weight buffers (5,248 B each; a workgroup is 51,200 + 20,992 = 72,192 B,
+// two workgroups per CU = 144 KB of the 160 KB).  Used wave-locally - no barrier, LDS operations of one wavefront execute
+// in order - for the two layout changes between "row-major in memory" and "accumulator layout in registers":
+//   * store: one 32-feature tile of the wave's 32 rows at a time (32 x 128 B at a 144-B pitch), written in accumulator
+//     layout, read back so that 8 lanes hold one row's 128 B: every global store instruction writes 8 whole cache lines
+//     instead of 64 16-B fragments in 32 lines;
+//   * message passing: 8 aggregated rows at a time (8 x 640 B at a 656-B pitch), written feature-on-lane by the
+//     gather, read back in B-operand layout.
+constexpr int STG_TILE_PITCH = 36;          // floats; 36 j mod 32 = 4 j: the 8 lanes of a ds_write_b128 group hit 32 banks once
+constexpr int STG_ROW_PITCH = 164;          // floats; 8 rows x 656 B
+constexpr int STG_ROWS = 8;
+constexpr int STG_FLOATS = STG_ROWS * STG_ROW_PITCH;       // 1,312 >= 32 * STG_TILE_PITCH
+static_assert(32 * STG_TILE_PITCH <= STG_FLOATS, "tile staging fits the per-wave area");
+constexpr int CHAIN_LDS_FLOATS = 2 * BUF_FLOATS + (WG / 64) * STG_FLOATS;
 
 struct Act { f32x16 t[5]; };
 
@@ -65,8 +81,8 @@ __device__ __forceinline__ void dma_copy(float* lds_dst, const float* __restrict
 
 // ------------------------------------------------------------------------------------------------ MFMA sweeps
 // chunks [Q0,Q1) of a layer whose LDS image starts at chunk Q0; input = previous accumulator tiles.
-// (Reading the fragments of chunk q+1 under the MFMAs of chunk q was measured: no gain - the second wavefront on the
-// SIMD already covers the LDS latency - and +20 VGPRs, which would evict the co-resident k_mp wavefront.)
+// (Reading the fragments of chunk q+1 under the MFMAs of chunk q was measured twice - with two MFMA-issuing wavefronts per
+// SIMD, and in the fused propagate chains where the partner wavefront is gathering half of the time: no gain, +20 VGPRs.)
 template <int Q0, int Q1, int MB>
 __device__ __forceinline__ void mma_act(const float* wl, const Act& in, f32x16* acc, int lane) {
 #pragma unroll
@@ -179,18 +195,52 @@ __device__ __forceinline__ void store_rows(const Act& a, float* __restrict__ bas
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Row-major store of the accumulator layout through the wave's LDS staging area, tile by tile.  `myrow`: the row
+// (of `base`, pitch NFP) that lane&31 of this wave owns; `valid`: whether that row exists.  Lane L stores, for every tile,
+// the 16-B piece (L&7) of the rows owned by lanes (L>>3) + 8i, i = 0..3: one instruction = 8 rows x 128 B, whole lines.
+__device__ __forceinline__ void store_rows_t(const Act& a, float* __restrict__ base, int myrow, bool valid, float* stg, int lane) {
+    const int j = lane & 31, h = lane >> 5, sr = lane >> 3, sc = lane & 7;
+    int srow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = __shfl(valid ? myrow : -1, sr + 8 * i, 64);
+        srow[i] = r;
+    }
+    float* wp = stg + j * STG_TILE_PITCH + 4 * h;
+    const float* rp = stg + sr * STG_TILE_PITCH + 4 * sc;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+            v[0] = a.t[t][4 * q + 0]; v[1] = a.t[t][4 * q + 1]; v[2] = a.t[t][4 * q + 2]; v[3] = a.t[t][4 * q + 3];
+            *reinterpret_cast<f32x4*>(wp + 8 * q) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rp + 8 * i * STG_TILE_PITCH);
+            if (srow[i] >= 0) *reinterpret_cast<f32x4*>(base + (long)srow[i] * NFP + 32 * t + 4 * sc) = v;
+        }
+    }
+    // keep the next layer's accumulator writes behind these stores (else the 80 source registers stay live under a
+    // renamed accumulator and the kernel spills)
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // One full 160-wide layer, weights streamed in four K-quarters through two LDS buffers.
 // Precondition: quarter 0 is in buffer 0 and a barrier has passed.  Every sweep runs with the NEXT quarter's
 // global->register loads in flight; the registers are written to the other buffer after the sweep.
 // Postcondition: the first NEXT floats of `next` (the following phase) are in buffer 0 and a barrier has passed.
-template <int NEXT, bool ZERO = true>
+// PRE: the caller has already issued the DMA of quarter 1 into buffer 1 (it did so BEFORE a burst of row stores: waits
+// count vector-memory operations in issue order, so a DMA issued behind the stores could not be awaited without them).
+template <int NEXT, bool ZERO = true, bool PRE = false>
 __device__ __forceinline__ void layer160(float* lds, const float* __restrict__ w, const float* __restrict__ next,
                                          const Act& in, Act& out, int tid, int lane) {
     float* b0 = lds;
     float* b1 = lds + BUF_FLOATS;
     if (ZERO) zero(out);                                     // else: accumulate on top of what `out` holds
     // every sweep runs with the NEXT quarter's DMA in flight into the other buffer (free since the last barrier)
-    dma_copy<Q_FLOATS>(b1, w + Q_FLOATS, tid);
+    if (!PRE) dma_copy<Q_FLOATS>(b1, w + Q_FLOATS, tid);
     mma_act<0, QCH, 5>(b0, in, out.t, lane);
     __syncthreads();
     dma_copy<Q_FLOATS>(b0, w + 2 * Q_FLOATS, tid);
@@ -213,7 +263,7 @@ __device__ __forceinline__ void stage_now(float* dst, const float* __restrict__ 
 struct GDev {
     const float* w;
     const float* node_in; const float* feat12; const float* group;
-    float* eff; float* P; float* U; float* V; float* agg; float* C;
+    float* eff; float* P; float* U; float* V; float* C;
     const int* recv; const int* send; const int* row_ptr; const int* n_edges;
     int B, N, n_p, n_inst, edge_cap, c_cap;
     float clamp; float* pred_pos; float* pred_motion;
@@ -222,10 +272,215 @@ struct GDev {
     long row0, nrows;          // k_node_enc: slice of rows to encode
     const int* ns_edge; const int* n_ns;   // k_edge_enc: non-self-loop edge list (null = every edge)
     const float* wb3;                      // bf16x3 weight image (null = exact fp32 mode)
+    // message passing fused into the propagate chains (gather_agg): inputs of THIS round (Uin/Vin: the class table in the
+    // first round of a rollout step, else what the previous round's chain wrote) - never the buffers this launch writes
+    const float* Uin; const float* Vin; const int* deg; int ell_stride; int dedupe; unsigned self_row; const int* n_guard;
+    int stagger_ticks; unsigned first_wave;   // see stagger_second_workgroup
     unsigned long long* dbg;   // diagnostic build of the clock probe only: 4 stamps per workgroup, never read by kernels
 };
 
 using WL = WeightLayout;
+
+// ------------------------------------------------------------------------------------------------ message passing
+// agg[i] = sum over edges e with recv(e) = i of ReLU(C[e] + U[i] + V[send(e)])
+//   = Rr^T.bmm(relation_propagator([rel_enc | eff_r | eff_s]))                       (reference model.py:312-324)
+// with W_rp factored as [W1|W2|W3]: C = W1*rel_enc + b, U = W2*eff, V = W3*eff.
+// Fused into the propagate chain: every wavefront aggregates the 32 rows it is about to push through Wb, so `agg` never
+// exists in HBM and the gather - HBM / L2 bound, no matrix work - of one workgroup runs under the MFMAs of the other
+// workgroup on the same CU (the two are kept half a period apart, see k_node_prop).
+// Shape: 8 rows at a time; the 8 lanes (c = lane&7) of a row read the eight 16-B pieces of one 128-B line, so a wave
+// instruction fetches 8 whole lines (C row of one edge of 8 different receivers, tile t); five tiles cover the 640-B
+// row.  Each lane sums its 4 features edge after edge in CSR (= reference nonzero) order: deterministic, no atomics,
+// bit-identical to a sequential segmented sum.  The 8 aggregated rows go to the wave's LDS staging area and come back
+// in B-operand layout (row on lane&31, features on registers).
+// Sender indices: the 8 lanes of a row load 8 consecutive indices with one instruction and hand them round with
+// ds_bpermute, so the index fetch is off the critical path of every edge but the first of a block.
+// Algorithmic bytes per receiver: deg*(640 C + 640 V + 4 idx) + 640 U.
+struct EdgeBuf { f32x4 c[5], v[5]; };
+// per-pass state of gather_agg that the load issue needs (all per lane; the row of this lane's 8-lane group)
+struct PassRow {
+    int i, deg, b, e0;       // particle, in-degree, candidate, first edge slot; everything else is re-derived per use
+};
+// issue the 10 loads of edge k of the lane's row (C row + V row, five 128-B tiles each, this lane's 16-B piece);
+// sj = the edge's sender
+__device__ __forceinline__ void gather_issue(const GDev& g, const PassRow& r, bool cls, int k, int sj, EdgeBuf& buf,
+                                             const float* __restrict__ C, const float* __restrict__ V, int lane) {
+    const unsigned c4 = 4u * (lane & 7);
+    const bool on = k < r.deg;
+    // lanes whose row has no edge k read the self-loop constant row and their own V row: valid addresses, values unused.
+    // Class-table rows (first round of a rollout step): a particle that takes part in an edge is valid by construction
+    // (masked pairs never pass the radius test, graph.py:253-256), so its row is a pure function of its index.
+    const unsigned selfrow = g.self_row + (r.i >= g.N_o ? 1u : 0u);          // C row of the self-loop constant
+    const unsigned crow = (!on || (g.dedupe && sj == r.i)) ? selfrow : (unsigned)r.b * (unsigned)g.c_cap + (unsigned)(r.e0 + k);
+    const unsigned tool0 = (unsigned)g.N_o + (unsigned)r.b * g.M;            // + particle index (>= N_o) = class row
+    const unsigned vrow = cls ? (sj >= g.N_o ? tool0 + (unsigned)sj : (unsigned)sj) : (unsigned)r.b * (unsigned)g.N + (unsigned)sj;
+    const float* cp = C + crow * (unsigned)NFP + c4;
+    const float* vp = V + vrow * (unsigned)NFP + c4;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        buf.c[t] = *reinterpret_cast<const f32x4*>(cp + 32 * t);
+        buf.v[t] = *reinterpret_cast<const f32x4*>(vp + 32 * t);
+    }
+}
+// acc += ReLU((c + u) + v) for the lanes whose row has this edge; a select, not a branch (adding +0 leaves a sum of
+// non-negative terms unchanged, and straight-line code lets the compiler count outstanding loads exactly)
+__device__ __forceinline__ void gather_consume(const EdgeBuf& buf, const f32x4* u, f32x4* acc, bool on) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float m = fmaxf((buf.c[t][e] + u[t][e]) + buf.v[t][e], 0.0f);
+            acc[t][e] += on ? m : 0.0f;
+        }
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v = max(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+__device__ __forceinline__ void gather_agg(const GDev& g, float* stg, long wave_row0, long nrows, Act& x, int lane) {
+    const int rr = lane >> 3, c = lane & 7, j = lane & 31, h = lane >> 5;
+    const bool cls = g.cls_on && g.first_round;
+    const float* __restrict__ C = g.C;
+    const float* __restrict__ U = g.Uin;
+    const float* __restrict__ V = g.Vin;
+    // per pass: this lane's receiver (candidate, first slot, degree) and its first block of sender indices (8 per block:
+    // lane c of a row holds index 8*block + c) - fetched up front so that only the C / V rows themselves are on the
+    // critical path of a pass
+    int pb[4], pe0[4], pdeg[4], pidx0[4], pkmax[4];
+    // Branch-free and batched: every load below has a clamped, always-valid address and is issued unconditionally, its
+    // value selected afterwards - two dependent round trips for the whole wave (slot-indexed rollout graphs: one,
+    // the sender indices do not depend on the degree) instead of two per pass behind divergent branches.
+    const long last_row = nrows - 1;
+    long prow[4]; bool prv[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const long row = wave_row0 + 8 * p + rr;
+        prv[p] = row < nrows;
+        prow[p] = prv[p] ? row : last_row;
+        pb[p] = (int)(prow[p] / g.N);
+    }
+    const bool ell = g.ell_stride != 0;                        // wave-uniform
+    int d0[4], d1[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = (int)(prow[p] - (long)pb[p] * g.N);
+        const int* dp = ell ? g.deg + prow[p] : g.row_ptr + (long)pb[p] * (g.N + 1) + i;
+        d0[p] = dp[0];
+        d1[p] = ell ? 0 : dp[1];                               // (deg is followed by other workspace arrays: in bounds)
+        if (ell) pe0[p] = i * g.ell_stride;
+    }
+    if (ell) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {                          // issued together with the degree loads
+            const long o = (long)pb[p] * g.edge_cap + min(pe0[p] + c, g.edge_cap - 1);
+            pidx0[p] = g.send[o];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int deg = ell ? d0[p] : d1[p] - d0[p];
+        if (!ell) pe0[p] = d0[p];
+        const int guard = g.n_guard ? g.n_guard[pb[p]] : 1;     // overflowed caller graph: row_ptr is not to be trusted
+        if (!prv[p] || guard == 0) deg = 0;
+        if (guard == 0) pe0[p] = 0;                             // its offsets are not to be followed either
+        pdeg[p] = deg;
+    }
+    if (!ell) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int e = min(max(pe0[p], 0) + c, g.edge_cap - 1);
+            pidx0[p] = g.send[(long)pb[p] * g.edge_cap + e];
+        }
+    }
+    auto row_of = [&](int p) {
+        PassRow r;
+        r.b = pb[p]; r.e0 = pe0[p]; r.deg = pdeg[p];
+        r.i = (int)(prow[p] - (long)pb[p] * g.N);
+        return r;
+    };
+    auto senders_of = [&](const PassRow& r) { return g.send + (long)r.b * g.edge_cap + r.e0; };
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (c >= pdeg[p]) pidx0[p] = (int)(prow[p] - (long)pb[p] * g.N);
+        pkmax[p] = wave_max(pdeg[p]);
+    }
+    const int N_o = g.N_o;
+    auto issue_u = [&](const PassRow& r, f32x4* u) {
+        const unsigned urow = cls ? (r.i >= N_o ? (unsigned)N_o + (unsigned)r.b * g.M + r.i : (unsigned)r.i)
+                                  : (unsigned)r.b * (unsigned)g.N + (unsigned)r.i;
+        const float* up = U + urow * (unsigned)NFP + 4u * c;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) u[t] = *reinterpret_cast<const f32x4*>(up + 32 * t);
+    };
+    // Rolling pipeline, one edge ahead: while edge k is summed, the 10 loads of edge k+1 are in flight in the other
+    // buffer; the U row and the first edge of the NEXT pass are issued before this pass's rows take their trip through
+    // LDS, so a pass boundary does not drain the memory pipe either.  The steady-state loop body is straight-line (no
+    // conditional issue, no other vector load), which is what lets the compiler wait with exact vmcnt(10)s.
+    constexpr int KFAST = 32;                                                  // edges per row served by the pipeline
+    f32x4 u[5];
+    EdgeBuf A, B;
+    PassRow r = row_of(0);
+    int idx0 = pidx0[0];
+    issue_u(r, u);
+    if (pkmax[0] > 0) gather_issue(g, r, cls, 0, __shfl(idx0, lane & 56, 64), A, C, V, lane);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int kmax = pkmax[p], kfast = min(kmax, KFAST);
+        // blocks 1..3 of the sender indices (rows with more than 8 edges: rope, the dense granular graphs); in flight
+        // from here, first used at edge 8
+        const int* snd = senders_of(r);
+        const int lastk = max(r.deg - 1, 0);
+        int idx1 = snd[min(8 + c, lastk)], idx2 = snd[min(16 + c, lastk)], idx3 = snd[min(24 + c, lastk)];
+        if (8 + c >= r.deg) idx1 = r.i;
+        if (16 + c >= r.deg) idx2 = r.i;
+        if (24 + c >= r.deg) idx3 = r.i;
+        auto sender = [&](int k) {
+            const int blk = k >> 3;                                            // wave-uniform
+            const int v = blk == 0 ? idx0 : blk == 1 ? idx1 : blk == 2 ? idx2 : idx3;
+            return __shfl(v, (lane & 56) + (k & 7), 64);
+        };
+        f32x4 acc[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 2 < kfast; k += 2) {
+            gather_issue(g, r, cls, k + 1, sender(k + 1), B, C, V, lane);
+            gather_consume(A, u, acc, k < r.deg);
+            gather_issue(g, r, cls, k + 2, sender(k + 2), A, C, V, lane);
+            gather_consume(B, u, acc, k + 1 < r.deg);
+        }
+        const int left = kfast - k;                                            // 0 (no edge at all), 1 or 2
+        if (left == 2) gather_issue(g, r, cls, k + 1, sender(k + 1), B, C, V, lane);
+        if (left >= 1) gather_consume(A, u, acc, k < r.deg);
+        if (left == 2) gather_consume(B, u, acc, k + 1 < r.deg);
+        for (k = KFAST; k < kmax; ++k) {                                       // rows beyond 32 edges: plain loop
+            const int sj = k < r.deg ? snd[k] : r.i;
+            gather_issue(g, r, cls, k, sj, A, C, V, lane);
+            gather_consume(A, u, acc, k < r.deg);
+        }
+        if (p + 1 < 4) {                                                       // next pass: U row and first edge
+            r = row_of(p + 1);
+            idx0 = pidx0[p + 1];
+            issue_u(r, u);
+            if (pkmax[p + 1] > 0) gather_issue(g, r, cls, 0, __shfl(idx0, lane & 56, 64), A, C, V, lane);
+        }
+        float* wp = stg + rr * STG_ROW_PITCH + 4 * c;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) *reinterpret_cast<f32x4*>(wp + 32 * t) = acc[t];
+        if ((j >> 3) == p) {
+            const float* rp = stg + (j & 7) * STG_ROW_PITCH + 4 * h;
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(rp + 32 * t + 8 * q);
+                    x.t[t][4 * q + 0] = v[0]; x.t[t][4 * q + 1] = v[1]; x.t[t][4 * q + 2] = v[2]; x.t[t][4 * q + 3] = v[3];
+                }
+        }
+    }
+}
 
 // class-table row of particle i of candidate b (see GraphBufs)
 __device__ __forceinline__ long cls_row(const GDev& g, int b, int i) {
@@ -233,11 +488,29 @@ __device__ __forceinline__ long cls_row(const GDev& g, int b, int i) {
     return g.vmask[(long)b * g.N + i] ? i : g.N_o + i;
 }
 
+// Two workgroups share a CU.  Each alternates a memory-bound phase (the gather) with a matrix-bound phase (the chain);
+// started together they stay in lockstep - both gathering, then both computing - and nothing overlaps.  Started half a
+// period apart, one gathers while the other has the matrix pipe to itself, and since both take equally long the offset
+// persists for every later workgroup that inherits their slots.  The offset is created once per launch: of the
+// workgroups resident from the start (blockIdx < first_wave: placement is breadth-first, measured with
+// tools/probes/wg_placement.hip) the one that was given the SECOND LDS allocation of its CU (LDS_BASE != 0 in
+// HW_REG_LDS_ALLOC) sleeps for `stagger_ticks` x 10 ns.  Speed only: any placement gives the same results.
+__device__ __forceinline__ void stagger_second_workgroup(const GDev& g) {
+    if (g.stagger_ticks > 0 && blockIdx.x < g.first_wave) {
+        const unsigned lds_base = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11));   // HW_REG_LDS_ALLOC[7:0]
+        if (lds_base != 0) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.stagger_ticks) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ edge chain
 // rel_inputs (17) -> Encoder(17,150,150) -> W1*enc + b_rp  => C      (model.py:249-282, 303, 317-318 first block)
 __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* stg = lds + 2 * BUF_FLOATS + wave * STG_FLOATS;
     // tile-major: block = tile * B + candidate.  Workgroups are dealt to XCDs / shader engines in a fixed rotation;
     // with candidate-major order every candidate's early-exit tail (tiles past its edge count) lands on the same
     // engines and the others carry all the work (measured: 16.7 % fewer rows, same kernel time).  Tile-major puts
@@ -290,7 +563,7 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
     layer160<Q_FLOATS>(lds, g.w + WL::E_L3, g.w + WL::E_W1, x, y, tid, lane);
     relu_one(y, lane);
     layer160<0>(lds, g.w + WL::E_W1, nullptr, y, x, tid, lane);
-    store_rows(x, g.C, (long)b * g.c_cap + el, lane, valid);
+    store_rows_t(x, g.C, (int)((long)b * g.c_cap + el), valid, stg, lane);
     if (g.dbg && tid == 0) {
         g.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
         g.dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -301,8 +574,9 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
 // p_inputs (6) -> Encoder(6,150,150) = p_enc => eff;  P = Wa*p_enc + b_pp;  U = W2*p_enc;  V = W3*p_enc
 // (model.py:297-298 and the particle_effect-dependent blocks of :317-318 / the particle_encode block of :328-330)
 __global__ __launch_bounds__(WG, 2) void k_node_enc(GDev g) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* stg = lds + 2 * BUF_FLOATS + wave * STG_FLOATS;
     const long rend = g.row0 + g.nrows;
     const long row = g.row0 + (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
     const bool valid = row < rend;
@@ -325,13 +599,13 @@ __global__ __launch_bounds__(WG, 2) void k_node_enc(GDev g) {
     relu_one(x, lane);
     layer160<Q_FLOATS>(lds, g.w + WL::N_L3, g.w + WL::N_WA, x, y, tid, lane);
     relu_one(y, lane);                                       // y = p_enc (slot 150 = 1 for the bias of Wa)
-    store_rows(y, g.eff, row, lane, valid);
+    store_rows_t(y, g.eff, (int)row, valid, stg, lane);
     layer160<Q_FLOATS>(lds, g.w + WL::N_WA, g.w + WL::N_W2, y, x, tid, lane);
-    store_rows(x, g.P, row, lane, valid);
+    store_rows_t(x, g.P, (int)row, valid, stg, lane);
     layer160<Q_FLOATS>(lds, g.w + WL::N_W2, g.w + WL::N_W3, y, x, tid, lane);
-    store_rows(x, g.U, row, lane, valid);
+    store_rows_t(x, g.U, (int)row, valid, stg, lane);
     layer160<0>(lds, g.w + WL::N_W3, nullptr, y, x, tid, lane);
-    store_rows(x, g.V, row, lane, valid);
+    store_rows_t(x, g.V, (int)row, valid, stg, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ propagate chain
@@ -340,21 +614,31 @@ __global__ __launch_bounds__(WG, 2) void k_node_enc(GDev g) {
 //   last:     motion = ParticlePredictor(eff) (model.py:44-61, 335); pred = cur + clamp(motion) (model.py:338)
 template <bool LAST>
 __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* stg = lds + 2 * BUF_FLOATS + wave * STG_FLOATS;
     const long nrows = (long)g.B * g.N;
     const long row = (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
     const bool valid = row < nrows;
     const long rowc = valid ? row : nrows - 1;
 
-    dma_copy<Q_FLOATS>(lds, g.w + WL::P_WB, tid);          // first quarter of Wb lands under the row loads
+    stagger_second_workgroup(g);
+    if (g.dbg && tid == 0) {
+        g.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));        // HW_REG_HW_ID: cu [11:8], se [15:13]
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));       // HW_REG_XCC_ID[3:0]
+        g.dbg[(unsigned long)gridDim.x * 4 + blockIdx.x] = (xcc << 8) | (((hw >> 13) & 7) << 4) | ((hw >> 8) & 15);
+    }
+    dma_copy<Q_FLOATS>(lds, g.w + WL::P_WB, tid);          // first quarter of Wb lands under the gather / row loads
     Act x, y;
     // The residual terms seed the accumulator: y = P + eff, then y += Wb*agg.  All three row loads are issued here,
     // together, instead of two of them stalling the chain after the Wb layer.
+    gather_agg(g, stg, (long)blockIdx.x * WG_ROWS + wave * 32, nrows, x, lane);
+    __builtin_amdgcn_sched_barrier(0);                       // nothing of what follows is worth a register during the gather
+    if (g.dbg && tid == 0) g.dbg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     const int pb = (int)(rowc / g.N), pi = (int)(rowc - (long)pb * g.N);
     const long crow = g.cls_on ? cls_row(g, pb, pi) : rowc;
     const bool ceff = g.cls_on && g.first_round;             // round 1: the previous effect is p_enc itself
-    load_rows(x, g.agg, rowc, lane);
     load_rows(y, g.cls_on ? g.c_P : g.P, crow, lane);
     // the third operand lands in temporaries: two batches keep it inside the register budget
     add_rows_part<0, 2>(y, ceff ? g.c_eff : g.eff, ceff ? crow : rowc, lane);
@@ -363,12 +647,18 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     __syncthreads();                                         // Wb quarter 0 is in buffer 0
     layer160<Q_FLOATS, false>(lds, g.w + WL::P_WB, g.w + (LAST ? WL::P_P0 : WL::N_W2), x, y, tid, lane);
     relu_one(y, lane);                                       // y = new particle effect (slot 150 forced to 1)
+    if (g.dbg && tid == 0) g.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
     if (!LAST) {
-        store_rows(y, g.eff, row, lane, valid);
-        layer160<Q_FLOATS>(lds, g.w + WL::N_W2, g.w + WL::N_W3, y, x, tid, lane);
-        store_rows(x, g.U, row, lane, valid);
-        layer160<0>(lds, g.w + WL::N_W3, nullptr, y, x, tid, lane);
-        store_rows(x, g.V, row, lane, valid);
+        // quarter 1 of the next layer is requested BEFORE each burst of row stores, so that the wait for it at the next
+        // barrier leaves the stores in flight: they then have two quarter sweeps to drain instead of one
+        dma_copy<Q_FLOATS>(lds + BUF_FLOATS, g.w + WL::N_W2 + Q_FLOATS, tid);
+        store_rows_t(y, g.eff, (int)row, valid, stg, lane);
+        layer160<Q_FLOATS, true, true>(lds, g.w + WL::N_W2, g.w + WL::N_W3, y, x, tid, lane);
+        dma_copy<Q_FLOATS>(lds + BUF_FLOATS, g.w + WL::N_W3 + Q_FLOATS, tid);
+        store_rows_t(x, g.U, (int)row, valid, stg, lane);
+        layer160<0, true, true>(lds, g.w + WL::N_W3, nullptr, y, x, tid, lane);
+        store_rows_t(x, g.V, (int)row, valid, stg, lane);
+        if (g.dbg && tid == 0) g.dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     } else {
         layer160<Q_FLOATS>(lds, g.w + WL::P_P0, g.w + WL::P_P1, y, x, tid, lane);
         relu_one(x, lane);
@@ -646,12 +936,14 @@ __global__ __launch_bounds__(WGB, 2) void k_node_prop_b3(GDev g) {
     const bool valid = row < nrows;
     const long rowc = valid ? row : nrows - 1;
     const float* W = g.wb3;
-    stream_begin<KIND>(lds, W, tid);
     Act x, y;
+    // fused message passing: the weight ring is not live yet, its first bytes serve as the per-wave staging areas
+    gather_agg(g, lds + wave * STG_FLOATS, (long)blockIdx.x * WGB_ROWS + wave * 32, nrows, x, lane);
+    __syncthreads();
+    stream_begin<KIND>(lds, W, tid);
     const int pb = (int)(rowc / g.N), pi = (int)(rowc - (long)pb * g.N);
     const long crow = g.cls_on ? cls_row(g, pb, pi) : rowc;
     const bool ceff = g.cls_on && g.first_round;
-    load_rows(x, g.agg, rowc, lane);
     load_rows(y, g.cls_on ? g.c_P : g.P, crow, lane);
     add_rows_part<0, 2>(y, ceff ? g.c_eff : g.eff, ceff ? crow : rowc, lane);
     materialize(y);
@@ -706,14 +998,19 @@ __global__ __launch_bounds__(WGB, 2) void k_node_prop_b3(GDev g) {
 // ------------------------------------------------------------------------------------------------ launchers
 static GDev to_dev(const float* w, const GraphBufs& g) {
     GDev d;
-    d.w = w; d.node_in = g.node_in; d.feat12 = g.feat12; d.group = g.group; d.eff = g.eff; d.P = g.P; d.U = g.U;
-    d.V = g.V; d.agg = g.agg; d.C = g.C; d.recv = g.recv; d.send = g.send; d.row_ptr = g.row_ptr;
+    d.w = w; d.node_in = g.node_in; d.feat12 = g.feat12; d.group = g.group; d.eff = g.eff; d.P = g.P; d.U = g.UV[1][0];
+    d.V = g.UV[1][1];; d.C = g.C; d.recv = g.recv; d.send = g.send; d.row_ptr = g.row_ptr;
     d.n_edges = g.n_edges; d.B = g.B; d.N = g.N; d.n_p = g.n_p; d.n_inst = g.n_inst; d.edge_cap = g.edge_cap;
     d.c_cap = g.c_cap; d.clamp = 0; d.pred_pos = nullptr; d.pred_motion = nullptr;
     d.cls_on = g.cls_on; d.N_o = g.N_o; d.M = g.M; d.first_round = 0; d.vmask = g.vmask; d.c_eff = g.c_eff; d.c_P = g.c_P;
     d.row0 = 0; d.nrows = (long)g.B * g.N;
     d.ns_edge = g.ns_edge; d.n_ns = g.n_ns;
     d.wb3 = g.wb3;
+    d.Uin = nullptr; d.Vin = nullptr; d.deg = g.deg; d.ell_stride = g.ell_stride; d.dedupe = g.c_self ? 1 : 0;
+    d.self_row = (unsigned)g.self_row; d.n_guard = g.n_guard;
+    // AG_STAGGER_US: offset between the two workgroups of a CU in the fused propagate chains (0 = off)
+    static const int stagger_us = getenv("AG_STAGGER_US") ? atoi(getenv("AG_STAGGER_US")) : 30;
+    d.stagger_ticks = stagger_us * 100; d.first_wave = 512;
     d.dbg = nullptr;
     return d;
 }
@@ -764,17 +1061,75 @@ hipError_t launch_node_enc(const float* w, const GraphBufs& g, long row0, long n
     else hipLaunchKernelGGL(k_node_enc, grid, dim3(WG), 0, st, d);
     return hipGetLastError();
 }
-hipError_t launch_node_prop(const float* w, const GraphBufs& g, int first_round, hipStream_t st) {
+// Round r of the message passing reads U/V of parity (r-1)&1 (the class table in the first round of a rollout step)
+// and writes parity r&1: a workgroup's gather must never see rows another workgroup of the same launch has rewritten.
+static void set_round(GDev& d, const GraphBufs& g, int round) {
+    const int first = round == 0;
+    d.first_round = first;
+    const bool cls = g.cls_on && first;
+    d.Uin = cls ? g.c_U : g.UV[(round - 1) & 1][0];         // round 0 without a class table: k_node_enc wrote parity 1
+    d.Vin = cls ? g.c_V : g.UV[(round - 1) & 1][1];
+    d.U = g.UV[round & 1][0]; d.V = g.UV[round & 1][1];
+}
+hipError_t launch_node_prop(const float* w, const GraphBufs& g, int round, hipStream_t st) {
     GDev d = to_dev(w, g);
-    d.first_round = first_round;
+    set_round(d, g, round);
+    // AG_NODE_PROBE=n : diagnostic mode (synchronises!): stamp the phases of the first n launches (s_memrealtime, 10 ns)
+    static int probe_left = getenv("AG_NODE_PROBE") ? atoi(getenv("AG_NODE_PROBE")) : 0;
+    static unsigned long long* dbg = nullptr;
+    static unsigned dbg_cap = 0;
+    const unsigned nwg = (unsigned)node_grid(g);
+    if (probe_left > 0 && !d.wb3) {
+        if (dbg_cap < nwg) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, (size_t)nwg * 40); dbg_cap = nwg; }
+        (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 40, st);
+        d.dbg = dbg;
+    }
     if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<false>, dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
-    else hipLaunchKernelGGL(k_node_prop<false>, dim3(node_grid(g)), dim3(WG), 0, st, d);
+    else hipLaunchKernelGGL(k_node_prop<false>, dim3(nwg), dim3(WG), 0, st, d);
+    if (d.dbg) {
+        --probe_left;
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h((size_t)nwg * 5);
+        (void)hipMemcpy(h.data(), dbg, (size_t)nwg * 40, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double a = 0, b = 0, c2 = 0; int n = 0;
+        for (unsigned i = 0; i < nwg; ++i) {
+            if (!h[4 * i + 3]) continue;
+            t0 = std::min(t0, h[4 * i]); t1 = std::max(t1, h[4 * i + 3]);
+            a += (double)(h[4 * i + 1] - h[4 * i]); b += (double)(h[4 * i + 2] - h[4 * i + 1]); c2 += (double)(h[4 * i + 3] - h[4 * i + 2]); ++n;
+        }
+        // per CU: how much of the launch had 0 / 1 / 2 workgroups in their chain phase (stamps 1..3), and in their gather
+        std::vector<std::vector<unsigned>> by_cu(2048);
+        for (unsigned i = 0; i < nwg; ++i) if (h[4 * i + 3]) by_cu[h[(size_t)nwg * 4 + i] & 0x7ff].push_back(i);
+        double chain[3] = {0, 0, 0}, gath[3] = {0, 0, 0}; int ncu = 0;
+        for (auto& v : by_cu) {
+            if (v.empty()) continue;
+            ++ncu;
+            std::vector<std::pair<unsigned long long, int>> ev, eg;
+            for (unsigned i : v) {
+                ev.push_back({h[4 * i + 1], +1}); ev.push_back({h[4 * i + 3], -1});
+                eg.push_back({h[4 * i + 0], +1}); eg.push_back({h[4 * i + 1], -1});
+            }
+            auto sweep = [&](std::vector<std::pair<unsigned long long, int>>& e, double* acc) {
+                std::sort(e.begin(), e.end());
+                int lvl = 0; unsigned long long prev = t0;
+                for (auto& x : e) { acc[std::min(lvl, 2)] += (double)(x.first - prev); prev = x.first; lvl += x.second; }
+                acc[0] += (double)(t1 - prev);
+            };
+            sweep(ev, chain); sweep(eg, gath);
+        }
+        const double span = (double)(t1 - t0) * ncu;
+        if (n) fprintf(stderr, "[ag node probe] round %d: %d workgroups on %d CUs, span %.1f us; mean per workgroup: gather+loads %.1f us, Wb layer %.1f us, "
+                               "W2+W3 layers+stores %.1f us | CU time with 0/1/2 workgroups in chain: %.0f%% %.0f%% %.0f%%; in gather: %.0f%% %.0f%% %.0f%%\n",
+                       round, n, ncu, (t1 - t0) * 0.01, a / n * 0.01, b / n * 0.01, c2 / n * 0.01,
+                       100 * chain[0] / span, 100 * chain[1] / span, 100 * chain[2] / span, 100 * gath[0] / span, 100 * gath[1] / span, 100 * gath[2] / span);
+    }
     return hipGetLastError();
 }
-hipError_t launch_node_final(const float* w, const GraphBufs& g, int first_round, float clamp, float* pred_pos,
+hipError_t launch_node_final(const float* w, const GraphBufs& g, int round, float clamp, float* pred_pos,
                              float* pred_motion, hipStream_t st) {
     GDev d = to_dev(w, g);
-    d.first_round = first_round;
+    set_round(d, g, round);
     d.clamp = clamp; d.pred_pos = pred_pos; d.pred_motion = pred_motion;
     if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<true>, dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
     else hipLaunchKernelGGL(k_node_prop<true>, dim3(node_grid(g)), dim3(WG), 0, st, d);

@@ -82,3 +82,20 @@ def sharded_rollout_costs(rollout_fn, cost_fn, actions: torch.Tensor, group=None
     lo, hi = bounds[rank]
     local = cost_fn(rollout_fn(actions[lo:hi], lo, hi), lo, hi)
     return all_gather_costs(local, actions.shape[0], group, bounds=bounds)
+
+
+def sharded_candidate_rewards(actions: torch.Tensor, rollout_fn, reward_fn, group=None) -> torch.Tensor:
+    """One MPC evaluation of a candidate batch sharded over the ranks of `group` - the step bench.py times.
+
+    actions (B, H, 4): the FULL batch, identical on every rank (same seed).  rollout_fn(actions_local) -> state_seqs of
+    the local shard; reward_fn(state_seqs, actions_local) -> (b,) rewards (any batch-global quantity inside it - the
+    error maximum of running_cost, the cloth penalty's distance maximum - must be all-reduced by the callee, cf.
+    losses._global_max).  Returns the (B,) reward vector of the whole batch on every rank: contiguous shards, one
+    all-gather of B/G floats per rank, nothing else crosses ranks."""
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    lo, hi = shard_bounds(actions.shape[0], world, rank)
+    local = actions[lo:hi]
+    rewards = reward_fn(rollout_fn(local), local)
+    return all_gather_costs(rewards.contiguous(), actions.shape[0], group)

@@ -194,15 +194,23 @@ def main():
     flag = torch.zeros(64, dtype=torch.int32, device=dev)
 
     last = {}
+    from adaptigraph_amd.sharding import sharded_candidate_rewards
+    actions_dev = actions.to(dev)
+
+    def rollout(a):
+        seq = ag.dynamics(state0, a, model, dev, ppm, _sync=False, _overflow_flag=flag)["state_seqs"]   # (b, H, N_o, 3)
+        last["seq"] = seq                                              # a reference, not a copy (parity_check below)
+        return seq
+
+    def reward(seq, a):
+        # running_cost (plan.py:27-59): the two batch-global maxima are all-reduced (MAX) when the batch is sharded
+        return ag.running_cost(seq, a, state0, error_func=err_fn, penalty_func=pen_fn, bbox=bbox,
+                               group=True if world > 1 else None)["reward_seqs"]
 
     def one_step():
-        out = ag.dynamics(state0, a_local, model, dev, ppm, _sync=False, _overflow_flag=flag)
-        seq = out["state_seqs"]                                        # (b, H, N_o, 3)
-        last["seq"] = seq                                              # a reference, not a copy (parity_check below)
-        # running_cost (plan.py:27-59): the two batch-global maxima are all-reduced (MAX) when the batch is sharded
-        rew = ag.running_cost(seq, a_local, state0, error_func=err_fn, penalty_func=pen_fn, bbox=bbox,
-                              group=True if world > 1 else None)["reward_seqs"]
-        return all_gather_costs(rew.contiguous(), B)                   # RCCL over xGMI: B/N fp32 per rank
+        # shard -> rollout -> rewards -> all-gather (RCCL over xGMI: B/N fp32 per rank); tests/test_sharding_gloo.py
+        # drives the same function with two gloo ranks
+        return sharded_candidate_rewards(actions_dev, rollout, reward)
 
     def sync_all():
         if world > 1:
@@ -234,9 +242,8 @@ def main():
     # ---- roofline pass: the same rollout once more with HIP events around every launch of the profiled kernels, on
     # the stream they are launched on.  Profiling pins the engine to ONE stream: with two chunks sharing the GPU an
     # event-bracketed duration measures the neighbour's kernels too.
-    fams = [] if args.no_kernel_profile else ["edge_enc", "mp"] if not args.profile_all else [
-        "edge_count", "edge_emit", "node_enc", "edge_enc", "mp", "node_prop", "node_final", "roll_init", "roll_update",
-        "cost"]
+    fams = [] if args.no_kernel_profile else ["edge_enc", "node_prop"] if not args.profile_all else [
+        "edge_count", "edge_emit", "node_enc", "edge_enc", "node_prop", "node_final", "roll_init", "roll_update", "cost"]
     prof_steps = 1
     eng.reset_stats()
     if fams:
@@ -315,28 +322,31 @@ def main():
         launches_per_step = max(1, n_edge // prof_steps)
         edges_per_launch = E_enc * (hi - lo) * H * R / launches_per_step
         avg_ms = ms_edge / max(1, n_edge)
-        traffic = None                                                 # PMC bytes per launch, measured off-line
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_k_edge_enc.json")
-        if os.path.exists(tpath):
+        def pmc_traffic(name, key, want):
+            """PMC bytes per launch, measured off-line with rocprofv3 --pmc (profiles/README.md); null when the committed
+            measurement was taken at another launch shape"""
+            tpath = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(tpath):
+                return None
             tj = json.load(open(tpath))
-            if abs(tj["edges_per_launch"] - edges_per_launch) / edges_per_launch < 0.01:
-                traffic = tj["hbm_bytes_per_launch"]
+            return tj["hbm_bytes_per_launch"] if abs(tj[key] - want) <= 0.01 * want else None
+
+        traffic = pmc_traffic("r02_traffic_k_edge_enc.json", "edges_per_launch", edges_per_launch)
         achieved = FLOP_PER_EDGE * edges_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        # second-largest family, the HBM-bound one: k_mp.  Compulsory HBM bytes per candidate and message-passing
-        # round: one 640-B C row per encoded edge and a 4-B index per edge, streamed once; the U and
-        # V tables in and agg out, 640 B per particle each (the per-edge V gathers re-read the V table out of L2).
-        # Three rounds per rollout step.
-        ms_mp, n_mp = fam_ms.get("mp", (0.0, 0))
-        mp_bytes_round = E_enc * 640 + E * 4 + (N_o + 1) * 1920
-        mp_bytes_launch = mp_bytes_round * (hi - lo) * H * R * 3 / max(1, n_mp // prof_steps)
-        mp_avg_ms = ms_mp / max(1, n_mp)
-        mp_gbs = mp_bytes_launch / (mp_avg_ms * 1e-3) / 1e9 if mp_avg_ms > 0 else 0.0
-        mp_traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_k_mp.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if n_mp and tj["candidates_per_launch"] == round((hi - lo) * H * R * 3 / max(1, n_mp // prof_steps)):
-                mp_traffic = tj["hbm_bytes_per_launch"]
+        # second-largest family: the propagate chain with the message passing fused into it (k_node_prop<false>, two
+        # launches per rollout step).  It is bounded by BOTH resources, so both fractions are reported: the matrix work
+        # (135,000 FLOP per particle) against the fp32 MFMA peak, and the compulsory HBM bytes against 8 TB/s - per
+        # candidate one 640-B C row per encoded edge and a 4-B index per edge, streamed once; the previous round's U, V
+        # and eff tables in, the new eff, U, V out (640 B per particle each; the per-edge V gathers re-read the V table
+        # out of L2 / Infinity Cache).
+        ms_np, n_np = fam_ms.get("node_prop", (0.0, 0))
+        cand_per_launch = (hi - lo) * H * R * 2 / max(1, n_np // prof_steps)
+        np_flop_launch = FLOP_PER_NODE_PROP * (N_o + 1) * cand_per_launch
+        np_bytes_launch = (E_enc * 640 + E * 4 + (N_o + 1) * 640 * 6) * cand_per_launch
+        np_avg_ms = ms_np / max(1, n_np)
+        np_tflops = np_flop_launch / (np_avg_ms * 1e-3) / 1e12 if np_avg_ms > 0 else 0.0
+        np_gbs = np_bytes_launch / (np_avg_ms * 1e-3) / 1e9 if np_avg_ms > 0 else 0.0
+        np_traffic = pmc_traffic("r02_traffic_k_node_prop.json", "candidates_per_launch", cand_per_launch)
         line = {
             "metric": "rollout-steps/sec", "value": total_steps * args.steps / dt, "unit": "rollout-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -356,12 +366,16 @@ def main():
                                         "note": "same kernel inside a normal two-stream rollout: the duration spans "
                                                 "whatever the other stream ran beside it (cf. the kernel trace of the "
                                                 "plain command); not a roofline measure"}},
-            "roofline_hbm_kernel": {"bound": "hbm", "kernel": "k_mp", "achieved": mp_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": mp_gbs / PEAK_HBM_GBS, "avg_launch_ms": mp_avg_ms, "launches": int(n_mp),
-                                    "bytes_per_launch": mp_bytes_launch, "traffic": mp_traffic,
-                                    "note": "second-largest kernel family; achieved = compulsory HBM bytes / HIP-event "
-                                            "time; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE per launch "
-                                            "(profiles/r01_traffic_k_mp.json): gathered V rows that miss L2 are the excess"},
+            "roofline_second_kernel": {"kernel": "k_node_prop<false> (propagate chain + fused message passing)",
+                                       "avg_launch_ms": np_avg_ms, "launches": int(n_np),
+                                       "mfma": {"achieved": np_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": np_tflops / PEAK_FP32_MFMA_TFLOPS, "flop_per_launch": np_flop_launch},
+                                       "hbm": {"achieved": np_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                               "frac": np_gbs / PEAK_HBM_GBS, "bytes_per_launch": np_bytes_launch,
+                                               "traffic": np_traffic},
+                                       "note": "the gather of one workgroup (HBM / L2 bound) runs beside the matrix work of "
+                                               "the other workgroup on its CU; achieved = algorithmic FLOPs resp. compulsory "
+                                               "HBM bytes / HIP-event time; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE per launch"},
             "kernel_ms_per_rollout_single_stream": {f: v[0] / prof_steps for f, v in fam_ms.items()},
         }
         # whole-rollout arithmetic rate: FLOPs the kernels execute per rollout step and candidate

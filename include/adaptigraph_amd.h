@@ -218,7 +218,8 @@ int ag_mppi_clip(ag_ctx* ctx, void* stream, const float* d_in, const float* d_lo
 
 /* Introspection for bench.py / tests: HIP-event time of every launch of a kernel family, recorded on the stream the
  * kernels run on.  family_mask bit i enables family i of: edge_count, edge_emit, prep, node_enc, edge_enc, mp,
- * node_prop, node_final, roll_init, roll_update (0 = off).  A non-zero mask pins the rollout to ONE stream so that a
+ * node_prop, node_final, roll_init, roll_update, cost (0 = off; "mp" is kept for index stability and never records: the
+ * message passing is fused into node_prop / node_final).  A non-zero mask pins the rollout to ONE stream so that a
  * duration measures the kernel alone; bit 30 keeps the streams instead (durations then include the other stream's
  * co-running kernels - what a kernel trace of a normal run shows).  ag_ctx_kernel_stats waits for the recorded
  * events and returns the total milliseconds and launch count since the last reset. */

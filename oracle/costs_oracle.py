@@ -68,6 +68,17 @@ def cloth_penalty(state_pred, action, state_init, sim_real_ratio=10.0):
     return (F32(1.0) - np.exp(-dmin * F32(100.0)) - dmax * F32(0.2)).astype(F32)
 
 
+def cloth_penalty_terms(state_pred, action, state_init, sim_real_ratio=10.0):
+    """The two per-(candidate, step) terms of losses.py:50-64 BEFORE the batch-global normalisation (:62) - what a rank
+    holding a shard of the batch can compute on its own: [exp(-dmin*100), dmax].  cloth_penalty = 1 - t0 - 0.2*t1/max(t1)."""
+    action, state_init = np.asarray(action, F32), np.asarray(state_init, F32)
+    pt = action[:, :, :2]
+    d = _norm_last(pt[:, :, None, :] - state_init[None, None][..., [0, 2]])
+    dmin = np.maximum(d.min(-1) - F32(0.005 * sim_real_ratio), 0)
+    dmax = np.minimum(d.max(-1), F32(0.4 * sim_real_ratio))
+    return np.stack([np.exp(-dmin * F32(100.0)), dmax], -1).astype(F32)
+
+
 def granular_penalty(state_pred, action, state_init, sim_real_ratio=10.0):
     """losses.py:66-92 -> (B,H): 9 points along the pusher blade."""
     state_pred, action, state_init = (np.asarray(a, F32) for a in (state_pred, action, state_init))

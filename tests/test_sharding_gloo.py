@@ -87,3 +87,65 @@ def test_two_rank_gloo_gather_matches_unsharded():
             p.join(timeout=60)
             assert p.exitcode == 0
         assert sorted(res) == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------------------------------------------- bench.py's step, 2 ranks
+def _mpc_step_worker(rank, world, port, B, q):
+    """The function bench.py times (sharding.sharded_candidate_rewards) with the engine replaced by its CPU oracle:
+    actions -> contiguous shard -> rollout -> running_cost with its two batch-global maxima all-reduced -> all-gather ->
+    every rank holds the same reward vector and picks the same best candidate as an unsharded evaluation."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import adaptigraph_oracle as O
+    from oracle import costs_oracle as Cc
+    from adaptigraph_amd.sharding import sharded_candidate_rewards
+    from adaptigraph_amd.losses import _global_max
+    rng = np.random.default_rng(3)                        # every rank builds the same inputs
+    W = O.random_weights(3)
+    task = dict(adj_thresh=0.75, topk=5, connect_tools_all=True, push_length=0.1, gripper_enable=True, eef_num=1,
+                pusher_points=[[0.0, 0.0, 0.17]], max_nR=4000, sim_real_ratio=10, n_his=4)
+    g = (np.arange(6) - 2.5) * 0.3
+    xx, zz = np.meshgrid(g, g, indexing="ij")
+    cloud = (np.stack([xx.ravel(), np.zeros(36), zz.ravel()], 1) + rng.normal(0, 0.02, (36, 3))).astype(np.float32)
+    target = (cloud + np.float32([0.3, 0, 0.2])).astype(np.float32)
+    acts = np.zeros((B, 2, 4), np.float32)
+    acts[..., 0] = rng.uniform(-0.8, 0.8, (B, 2))
+    acts[..., 1] = rng.uniform(-0.8, 0.8, (B, 2))
+    acts[..., 2] = rng.uniform(-3, 3, (B, 2))
+    acts[..., 3] = rng.integers(1, 3, (B, 2)) + 0.5
+    actions = torch.from_numpy(acts)
+
+    def rollout(a):
+        return torch.from_numpy(O.dynamics(W, 3, cloud, a.numpy(), task)["state_seqs"])
+
+    def make_reward(group):
+        def reward(seq, a):                               # running_cost (plan.py:27-59) with the cloth objective
+            s = seq.numpy()
+            b, H = s.shape[:2]
+            err = torch.from_numpy(Cc.chamfer(s.reshape(b * H, -1, 3), target[None]).reshape(b, H).astype(np.float32))
+            w = (2.0 / (_global_max(err, group).to(torch.float64) + 1e-6)).to(torch.float32)          # plan.py:37
+            raw = torch.from_numpy(Cc.cloth_penalty_terms(s, a.numpy(), cloud, 10.0))                 # (b,H,2)
+            pen = 1.0 - raw[..., 0] - raw[..., 1] / _global_max(raw[..., 1], group) * 0.2              # losses.py:62-63
+            return -w * err[:, -1] - 5.0 * pen.mean(1)
+        return reward
+
+    full = sharded_candidate_rewards(actions, rollout, make_reward(True))
+    want = make_reward(None)(rollout(actions), actions)   # unsharded, on this rank alone
+    ok = full.shape == (B,) and torch.equal(full, want) and int(torch.argmax(full)) == int(torch.argmax(want))
+    q.put((rank, bool(ok), int(torch.argmax(full))))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_mpc_step_matches_unsharded():
+    ctx = mp.get_context("spawn")
+    B = 7                                                 # uneven split: 4 + 3 candidates
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mpc_step_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[:2] for r in res] == [(0, True), (1, True)] and res[0][2] == res[1][2]
