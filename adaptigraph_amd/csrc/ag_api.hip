@@ -201,6 +201,7 @@ struct Work {
     int* ell; int* deg; int* slice_tot; int* cta_flag;
     int* recv; int* send; int* row_ptr; int* n_edges;
     int* ns_edge; int* n_ns;
+    int* rowlist; int* n_rows;   // ragged batches (GraphBufs::rowlist)
 };
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
@@ -222,7 +223,7 @@ size_t work_bytes(int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices
     size_t bytes = 16 * 256;
     bytes += rows * (NODE_IN + F12 + (own_group ? n_inst : 0)) * 4 + 6 * rows * NFP * 4 + ((size_t)Bc * c_cap + 256) * NFP * 4;
     if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 3) * 4 + 3 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
-    if (roll) bytes += (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
+    if (roll) bytes += rows * 4 + 1024 + (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
                        (size_t)cls_rows(N_o, N - N_o, Bc) * (NODE_IN + 4 * NFP) * 4;
     return bytes + 64 * 256;
 }
@@ -255,6 +256,8 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
         w.g.recv = w.recv; w.g.send = w.send; w.g.row_ptr = w.row_ptr; w.g.n_edges = w.n_edges;
     }
     if (roll) {
+        w.rowlist = s.take<int>(rows);
+        w.n_rows = s.take<int>(64);
         w.r.hist = s.take<float>((size_t)Bc * N_HIS * N * 3);
         w.r.pred = s.take<float>((size_t)Bc * N_o * 3);
         w.r.motion = s.take<float>((size_t)Bc * N_o * 3);
@@ -651,12 +654,18 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     if (p->B <= 1) ns = 1;
     const int slices = pick_slices(Bc, N);
     const int ell = edge_ell_stride(N, p->topk);
-    const size_t wb = work_bytes(Bc, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
+    // Ragged batches (the masked variant: every candidate has its own number of valid particles): the propagate chains
+    // walk a compact row list, and one extra candidate slot per workspace - the phantom candidate, see GraphBufs - stands
+    // for every masked-out particle.  AG_NO_RAGGED=1 keeps the dense rows (A/B measurements).
+    const bool ragged_env = !(getenv("AG_NO_RAGGED") && atoi(getenv("AG_NO_RAGGED")));      // read per call (tests toggle it)
+    const bool ragged = ragged_env && p->y_mode == 1 && d_obj_mask != nullptr;
+    const int Ba = Bc + (ragged ? 1 : 0);                    // candidate slots per workspace
+    const size_t wb = work_bytes(Ba, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
     rc = ensure_slab(c, wb * ns);
     if (rc) return rc;
     Work ws[ag_ctx::kMaxStreams] = {};
     for (int i = 0; i < ns; ++i) {
-        rc = carve_work(c, ws[i], Bc, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
+        rc = carve_work(c, ws[i], Ba, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
         if (rc) return rc;
     }
     hipStream_t streams[ag_ctx::kMaxStreams] = {st, st, st, st};
@@ -692,7 +701,7 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         static const bool dedupe = !(getenv("AG_NO_SELF_DEDUPE") && atoi(getenv("AG_NO_SELF_DEDUPE")));
         if (dedupe) {
             g.c_self = c->d_cself; g.ns_edge = w.ns_edge; g.n_ns = w.n_ns;
-            g.self_row = (long)Bc * edge_cap;     // behind the last candidate's C rows of this workspace
+            g.self_row = (long)Ba * edge_cap;     // behind the last candidate's C rows of this workspace
             HIPCHK(c, hipMemcpyAsync(w.g.C + (size_t)g.self_row * NFP, c->d_cself, 2 * NFP * 4, hipMemcpyDeviceToDevice, cs));
         }
         RollArgs ra{};
@@ -711,6 +720,12 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
             ea.ell_full = 1; ea.ell = w.send; ea.ell_stride = k + p->M; ea.ell_bstride = edge_cap;
             ea.ns_edge = w.ns_edge; ea.n_ns = w.n_ns;
             g.deg = w.deg; g.ell_stride = k + p->M;
+        }
+        w.r.ragged = ragged ? 1 : 0; w.r.clamp = c->dims.motion_clamp;
+        if (ragged) {   // the mask does not change during a rollout: one work list per chunk and call
+            HIPCHK(c, launch_build_rowlist(d_obj_mask, b0, nb, p->N_o, p->M, w.rowlist, w.n_rows, w.r.mask, w.deg, cs));
+            HIPCHK(c, hipMemsetAsync(w.row_ptr + (size_t)nb * (N + 1), 0, (size_t)(N + 1) * 4, cs));   // CSR path: no edges
+            g.rowlist = w.rowlist; g.n_rows = w.n_rows;
         }
         for (int li = 0; li < p->H; ++li) {
             int max_rep = 0;

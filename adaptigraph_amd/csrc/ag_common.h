@@ -136,6 +136,13 @@ struct GraphBufs {
     const int* ns_edge; const int* n_ns;   // (B,edge_cap), (B,) or null
     const float* wb3;                      // bf16x3 weight image: non-null selects the bf16x3 chains (ag_mlp.hip)
     const int* n_guard;                    // ag_forward: guarded per-candidate edge counts (k_edge_guard), else null
+    // ---- ragged batches (masked rollouts, forward_dynamics.py:286-309: every candidate has its own number of valid
+    // particles).  The propagate chains walk `rowlist` (dense rows b*N + i of the valid object particles and the tools,
+    // ascending) instead of all B*N rows.  A masked-out particle takes part in no edge and its node input does not depend
+    // on the candidate, so what the reference computes for it (model.py:338: pos + clamp(motion), a constant motion per
+    // particle index) is computed ONCE, on the rows of a phantom candidate B (all particles masked out, no tools, no
+    // edges) appended to the list; k_roll_update applies it to the masked-out rows of every real candidate.
+    const int* rowlist; const int* n_rows; // (B*N + N_o,), (1,) device; null = all rows
 };
 constexpr int B3_PHASE_BYTES = 2 * 5 * 3 * 64 * 16;   // 30,720
 constexpr int B3_PHASES = 58;
@@ -156,7 +163,10 @@ hipError_t launch_prep(const float* state, const float* attrs, const float* acti
 struct RollBufs {
     float* hist;        // (B, N_HIS, N, 3)
     float* pred;        // (B, N_o, 3) latest prediction
-    float* motion;      // (B, N_o, 3) latest raw motion (not consumed by the rollout)
+    float* motion;      // (B, N_o, 3) latest raw motion; ragged batches: row block B = the phantom candidate's motion, i.e.
+                        // the constant motion of a masked-out particle per particle index
+    int ragged;         // masked rollout with a work list (GraphBufs::rowlist)
+    float clamp;        // model.py:86 motion clamp, for the masked-out rows
     uint8_t* mask;      // (B,N) valid particles incl. tools
     uint8_t* tool;      // (B,N)
 };
@@ -186,6 +196,10 @@ hipError_t launch_mppi_update(const float* acts, const float* reward, const floa
                               float rw, float pl, float* out, hipStream_t st);
 hipError_t launch_mppi_clip(const float* in, const float* lo, const float* hi, float* out, long n, hipStream_t st);
 
+// work list of a ragged batch (see GraphBufs::rowlist): valid rows of candidates [0,B) + phantom rows if any particle is
+// masked out; also clears the phantom candidate's mask and degree rows
+hipError_t launch_build_rowlist(const uint8_t* obj_mask, int b0, int B, int N_o, int M, int* rowlist, int* n_rows,
+                                uint8_t* mask, int* deg, hipStream_t st);
 hipError_t launch_roll_init(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);
 hipError_t launch_roll_update(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);
 

@@ -64,6 +64,7 @@ hipError_t launch_prep(const float* state, const float* attrs, const float* acti
 struct RollDev {
     RollArgs a;
     float* hist; float* pred; uint8_t* mask; uint8_t* tool;
+    const float* motion_inv; float clamp;   // ragged batches: constant motion of a masked-out particle per index, or null
     float* node_in; float* feat12; float* group; int n_inst;
     float* c_node_in; int write_obj_cls;   // class-table inputs (GraphBufs): tool rows every init, object rows on demand
 };
@@ -182,8 +183,22 @@ __global__ __launch_bounds__(RT) void k_roll_update(RollDev d) {
     const RollArgs& a = d.a;
     const int b = blockIdx.x, bg = a.b0 + b, tid = threadIdx.x;
     const int N = a.N_o + a.M;
-    const float* pred = d.pred + (long)b * a.N_o * 3;
+    float* pred = d.pred + (long)b * a.N_o * 3;
     const uint8_t* om = a.obj_mask ? a.obj_mask + (long)bg * a.N_o : nullptr;
+    if (d.motion_inv && om) {
+        // ragged batch: the chains skipped the masked-out particles.  What the reference computes for them (model.py:338:
+        // last position + clamped motion; they receive no edge, so the motion is a constant of the model per particle
+        // index) was computed once on the phantom candidate's rows: apply it here.
+        for (int i = tid; i < a.N_o; i += RT) {
+            if (om[i]) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float cur = d.hist[(((long)b * N_HIS + (N_HIS - 1)) * N + i) * 3 + c];
+                pred[3 * i + c] = cur + fminf(fmaxf(d.motion_inv[3 * i + c], -d.clamp), d.clamp);
+            }
+        }
+        __syncthreads();
+    }
     if (a.repeat[(long)bg * a.H + a.li] == a.ai) {           // :160-161
         float* out = a.state_seqs + ((long)bg * a.H + a.li) * a.N_o * 3;
         for (int k = tid; k < a.N_o * 3; k += RT) out[k] = pred[k];
@@ -226,9 +241,55 @@ __global__ __launch_bounds__(RT) void k_roll_update(RollDev d) {
     }
 }
 
+// Work list of a ragged batch (GraphBufs::rowlist).  One workgroup; rows in ascending dense order: for every candidate its
+// valid object particles, then its tools; then - only if some particle of the chunk is masked out - the N_o object rows of
+// the phantom candidate B.  Also clears what the chains read of the phantom candidate (validity mask, in-degrees).
+__global__ __launch_bounds__(RT) void k_build_rowlist(const uint8_t* __restrict__ obj_mask, int b0, int B, int N_o, int M,
+                                                       int* __restrict__ rowlist, int* __restrict__ n_rows,
+                                                       uint8_t* __restrict__ mask, int* __restrict__ deg) {
+    __shared__ int scan[RT];
+    __shared__ int base;
+    const int tid = threadIdx.x, N = N_o + M;
+    if (tid == 0) base = 0;
+    for (int i = tid; i < N; i += RT) { mask[(long)B * N + i] = 0; if (deg) deg[(long)B * N + i] = 0; }
+    __syncthreads();
+    const long total = (long)B * N;
+    for (long r0 = 0; r0 < total; r0 += RT) {
+        const long r = r0 + tid;
+        int v = 0;
+        if (r < total) {
+            const int b = (int)(r / N), i = (int)(r - (long)b * N);
+            v = (i >= N_o || obj_mask[(long)(b0 + b) * N_o + i]) ? 1 : 0;
+        }
+        scan[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < RT; off <<= 1) {
+            int t = 0;
+            if (tid >= off) t = scan[tid - off];
+            __syncthreads();
+            scan[tid] += t;
+            __syncthreads();
+        }
+        if (v) rowlist[base + scan[tid] - 1] = (int)r;
+        __syncthreads();
+        if (tid == RT - 1) base += scan[RT - 1];
+        __syncthreads();
+    }
+    const int n_valid = base;
+    const bool any_invalid = n_valid < total;
+    if (any_invalid) for (int i = tid; i < N_o; i += RT) rowlist[n_valid + i] = (int)(total + i);
+    if (tid == 0) n_rows[0] = n_valid + (any_invalid ? N_o : 0);
+}
+hipError_t launch_build_rowlist(const uint8_t* obj_mask, int b0, int B, int N_o, int M, int* rowlist, int* n_rows,
+                                uint8_t* mask, int* deg, hipStream_t st) {
+    hipLaunchKernelGGL(k_build_rowlist, dim3(1), dim3(RT), 0, st, obj_mask, b0, B, N_o, M, rowlist, n_rows, mask, deg);
+    return hipGetLastError();
+}
+
 static RollDev to_dev(const RollArgs& a, const RollBufs& r, const GraphBufs& g) {
     RollDev d;
     d.a = a; d.hist = r.hist; d.pred = r.pred; d.mask = r.mask; d.tool = r.tool;
+    d.motion_inv = r.ragged ? r.motion + (long)a.B * a.N_o * 3 : nullptr; d.clamp = r.clamp;
     d.node_in = g.node_in; d.feat12 = g.feat12; d.group = g.group; d.n_inst = g.n_inst;
     d.c_node_in = g.cls_on ? g.c_node_in : nullptr; d.write_obj_cls = a.write_obj_cls;
     return d;

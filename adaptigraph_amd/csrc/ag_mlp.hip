@@ -276,6 +276,10 @@ struct GDev {
     // first round of a rollout step, else what the previous round's chain wrote) - never the buffers this launch writes
     const float* Uin; const float* Vin; const int* deg; int ell_stride; int dedupe; unsigned self_row; const int* n_guard;
     int stagger_ticks; unsigned first_wave;   // see stagger_second_workgroup
+    // ragged batches (masked rollouts): the propagate chains walk a compact list of the rows that exist - valid object
+    // particles and tools, plus one phantom candidate that stands for every masked-out particle (GraphBufs) - instead of
+    // all B*N rows; rowlist[slot] = dense row b*N + i, *n_rows = number of slots.  Null: every dense row, in order.
+    const int* rowlist; const int* n_rows;
     unsigned long long* dbg;   // diagnostic build of the clock probe only: 4 stamps per workgroup, never read by kernels
 };
 
@@ -296,6 +300,12 @@ using WL = WeightLayout;
 // Sender indices: the 8 lanes of a row load 8 consecutive indices with one instruction and hand them round with
 // ds_bpermute, so the index fetch is off the critical path of every edge but the first of a block.
 // Algorithmic bytes per receiver: deg*(640 C + 640 V + 4 idx) + 640 U.
+// work-list slot -> dense row (b*N + i); slots past the end repeat the last one (their results are never stored)
+__device__ __forceinline__ long dense_row(const GDev& g, long slot, long nslots) {
+    const long s = slot < nslots ? slot : nslots - 1;
+    return g.rowlist ? (long)g.rowlist[s] : s;
+}
+
 struct EdgeBuf { f32x4 c[5], v[5]; };
 // per-pass state of gather_agg that the load issue needs (all per lane; the row of this lane's 8-lane group)
 struct PassRow {
@@ -352,13 +362,12 @@ __device__ __forceinline__ void gather_agg(const GDev& g, float* stg, long wave_
     // Branch-free and batched: every load below has a clamped, always-valid address and is issued unconditionally, its
     // value selected afterwards - two dependent round trips for the whole wave (slot-indexed rollout graphs: one,
     // the sender indices do not depend on the degree) instead of two per pass behind divergent branches.
-    const long last_row = nrows - 1;
     long prow[4]; bool prv[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const long row = wave_row0 + 8 * p + rr;
-        prv[p] = row < nrows;
-        prow[p] = prv[p] ? row : last_row;
+        const long slot = wave_row0 + 8 * p + rr;
+        prv[p] = slot < nrows;
+        prow[p] = dense_row(g, slot, nrows);
         pb[p] = (int)(prow[p] / g.N);
     }
     const bool ell = g.ell_stride != 0;                        // wave-uniform
@@ -617,10 +626,12 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* stg = lds + 2 * BUF_FLOATS + wave * STG_FLOATS;
-    const long nrows = (long)g.B * g.N;
-    const long row = (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
-    const bool valid = row < nrows;
-    const long rowc = valid ? row : nrows - 1;
+    const long nrows = g.n_rows ? (long)*g.n_rows : (long)g.B * g.N;     // work-list slots (== dense rows without a list)
+    if ((long)blockIdx.x * WG_ROWS >= nrows) return;                      // whole workgroup past the end of a ragged batch
+    const long slot = (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
+    const bool valid = slot < nrows;
+    const long rowc = dense_row(g, slot, nrows);
+    const long row = rowc;
 
     stagger_second_workgroup(g);
     if (g.dbg && tid == 0) {
@@ -931,10 +942,12 @@ __global__ __launch_bounds__(WGB, 2) void k_node_prop_b3(GDev g) {
     __shared__ __attribute__((aligned(16))) float lds[NSLOT * UNIT_FLOATS];
     constexpr int KIND = LAST ? 3 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long nrows = (long)g.B * g.N;
-    const long row = (long)blockIdx.x * WGB_ROWS + wave * 32 + (lane & 31);
-    const bool valid = row < nrows;
-    const long rowc = valid ? row : nrows - 1;
+    const long nrows = g.n_rows ? (long)*g.n_rows : (long)g.B * g.N;
+    if ((long)blockIdx.x * WGB_ROWS >= nrows) return;
+    const long slot = (long)blockIdx.x * WGB_ROWS + wave * 32 + (lane & 31);
+    const bool valid = slot < nrows;
+    const long rowc = dense_row(g, slot, nrows);
+    const long row = rowc;
     const float* W = g.wb3;
     Act x, y;
     // fused message passing: the weight ring is not live yet, its first bytes serve as the per-wave staging areas
@@ -1008,14 +1021,17 @@ static GDev to_dev(const float* w, const GraphBufs& g) {
     d.wb3 = g.wb3;
     d.Uin = nullptr; d.Vin = nullptr; d.deg = g.deg; d.ell_stride = g.ell_stride; d.dedupe = g.c_self ? 1 : 0;
     d.self_row = (unsigned)g.self_row; d.n_guard = g.n_guard;
+    d.rowlist = g.rowlist; d.n_rows = g.n_rows;
     // AG_STAGGER_US: offset between the two workgroups of a CU in the fused propagate chains (0 = off)
     static const int stagger_us = getenv("AG_STAGGER_US") ? atoi(getenv("AG_STAGGER_US")) : 30;
     d.stagger_ticks = stagger_us * 100; d.first_wave = 512;
     d.dbg = nullptr;
     return d;
 }
-static int node_grid(const GraphBufs& g) { return (int)(((long)g.B * g.N + WG_ROWS - 1) / WG_ROWS); }
-static int node_grid_b3(const GraphBufs& g) { return (int)(((long)g.B * g.N + WGB_ROWS - 1) / WGB_ROWS); }
+// upper bound of the work-list length: every dense row, plus the phantom candidate's object rows of a ragged batch
+static long node_slots(const GraphBufs& g) { return (long)g.B * g.N + (g.rowlist ? g.N_o : 0); }
+static int node_grid(const GraphBufs& g) { return (int)((node_slots(g) + WG_ROWS - 1) / WG_ROWS); }
+static int node_grid_b3(const GraphBufs& g) { return (int)((node_slots(g) + WGB_ROWS - 1) / WGB_ROWS); }
 
 hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
     const long rows = (long)g.B * g.c_cap;

@@ -587,3 +587,41 @@ def test_failed_rollout_joins_its_streams_and_leaves_the_ctx_usable(ag, O, dev):
     assert torch.equal(again, good)
     _, fresh = _model(ag, O, "cloth", 29, dev)
     assert torch.equal(ag.dynamics(s0, a, fresh, dev, _ppm(task, "cloth"))["state_seqs"], good)
+
+
+@pytest.mark.parametrize("topk", [10, 500])
+def test_ragged_row_list_equals_dense_rows_bitwise(ag, O, dev, topk):
+    """Masked batches run the propagate chains over a compact row list + one phantom candidate for the masked-out
+    particles; AG_NO_RAGGED=1 runs all B x N rows as before.  Same bits for EVERY row, masked-out ones included (the
+    reference moves those too, model.py:338), with masks that have holes, an all-valid and a nearly empty candidate;
+    topk 500 takes the CSR (radius-only) graph path."""
+    import os
+    rng = np.random.default_rng(61)
+    task = _task("rope", max_nR=20000, topk=topk, adj_thresh=0.5 if topk == 10 else 0.12)
+    W, m = _model(ag, O, "rope", 61, dev)
+    B, n = 7, 150
+    state = np.zeros((B, n, 3), np.float32)
+    mask = np.zeros((B, n), bool)
+    keep = [1.0, 0.8, 0.5, 0.97, 0.3, 1.0, 0.02]
+    for b in range(B):
+        state[b] = _rope(n, rng)
+        mask[b] = rng.uniform(size=n) < keep[b]
+        mask[b, 0] = True
+        state[b, ~mask[b]] = rng.normal(0, 1, (int((~mask[b]).sum()), 3))      # padding rows need not be zero
+    a = _actions(state[0], B, 1, [3, 2, 4, 1, 5, 2, 3], rng)[:, 0]
+    args = (torch.from_numpy(state).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(a).to(dev))
+    ragged = ag.dynamics_masked(*args, m, dev, _ppm(task, "rope"))["state_seqs"]
+    os.environ["AG_NO_RAGGED"] = "1"
+    try:
+        dense = ag.dynamics_masked(*args, m, dev, _ppm(task, "rope"))["state_seqs"]
+    finally:
+        del os.environ["AG_NO_RAGGED"]
+    assert torch.isfinite(ragged).all() and torch.equal(ragged, dense)
+    m.engine(dev).set_chunk(3)                                          # phantom slot moves with the chunk size
+    try:
+        chunked = ag.dynamics_masked(*args, m, dev, _ppm(task, "rope"))["state_seqs"]
+    finally:
+        m.engine(dev).set_chunk(0)
+    assert torch.equal(chunked, dense)
+    want = O.dynamics_masked(W, 3, state, mask, a, task)["state_seqs"]
+    assert np.abs(ragged.cpu().numpy() - want).max() <= POS_TOL
