@@ -639,6 +639,7 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));        // HW_REG_HW_ID: cu [11:8], se [15:13]
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));       // HW_REG_XCC_ID[3:0]
         g.dbg[(unsigned long)gridDim.x * 4 + blockIdx.x] = (xcc << 8) | (((hw >> 13) & 7) << 4) | ((hw >> 8) & 15);
+        g.dbg[(unsigned long)gridDim.x * 5 + 2 * blockIdx.x] = __builtin_amdgcn_s_memtime();
     }
     dma_copy<Q_FLOATS>(lds, g.w + WL::P_WB, tid);          // first quarter of Wb lands under the gather / row loads
     Act x, y;
@@ -669,7 +670,10 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
         store_rows_t(x, g.U, (int)row, valid, stg, lane);
         layer160<0, true, true>(lds, g.w + WL::N_W3, nullptr, y, x, tid, lane);
         store_rows_t(x, g.V, (int)row, valid, stg, lane);
-        if (g.dbg && tid == 0) g.dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        if (g.dbg && tid == 0) {
+            g.dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+            g.dbg[(unsigned long)gridDim.x * 5 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+        }
     } else {
         layer160<Q_FLOATS>(lds, g.w + WL::P_P0, g.w + WL::P_P1, y, x, tid, lane);
         relu_one(x, lane);
@@ -1095,18 +1099,51 @@ hipError_t launch_node_prop(const float* w, const GraphBufs& g, int round, hipSt
     static unsigned long long* dbg = nullptr;
     static unsigned dbg_cap = 0;
     const unsigned nwg = (unsigned)node_grid(g);
+    // AG_NODE_PROBE=-1: stamp EVERY launch without synchronising (each overwrites the last) and report the in-kernel clock of
+    // the final launch at process exit: the clock the chip holds in the middle of a sustained run
+    static bool probe_tail = getenv("AG_NODE_PROBE") && atoi(getenv("AG_NODE_PROBE")) < 0;
+    if (probe_tail && !d.wb3) {
+        static unsigned tail_nwg = 0;
+        if (dbg_cap < nwg) {
+            if (dbg) (void)hipFree(dbg);
+            (void)hipMalloc((void**)&dbg, (size_t)nwg * 56); dbg_cap = nwg;
+            (void)hipMemset(dbg, 0, (size_t)nwg * 56);
+            static bool reg = false;
+            if (!reg) {
+                reg = true;
+                atexit([]() {
+                    (void)hipDeviceSynchronize();
+                    std::vector<unsigned long long> h((size_t)tail_nwg * 7);
+                    (void)hipMemcpy(h.data(), dbg, (size_t)tail_nwg * 56, hipMemcpyDeviceToHost);
+                    double ghz = 0; int n = 0;
+                    for (unsigned i = 0; i < tail_nwg; ++i) {
+                        const unsigned long long c0 = h[(size_t)tail_nwg * 5 + 2 * i], c1 = h[(size_t)tail_nwg * 5 + 2 * i + 1];
+                        if (c1 > c0 && h[4 * i + 3] > h[4 * i]) { ghz += (double)(c1 - c0) / (double)(h[4 * i + 3] - h[4 * i]) * 0.1; ++n; }
+                    }
+                    if (n) fprintf(stderr, "[ag node probe] last k_node_prop<false> launch of the process: in-kernel clock %.3f GHz over %d workgroups\n", ghz / n, n);
+                });
+            }
+        }
+        tail_nwg = nwg;
+        d.dbg = dbg;
+    }
     if (probe_left > 0 && !d.wb3) {
-        if (dbg_cap < nwg) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, (size_t)nwg * 40); dbg_cap = nwg; }
-        (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 40, st);
+        if (dbg_cap < nwg) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, (size_t)nwg * 56); dbg_cap = nwg; }
+        (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 56, st);
         d.dbg = dbg;
     }
     if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<false>, dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
     else hipLaunchKernelGGL(k_node_prop<false>, dim3(nwg), dim3(WG), 0, st, d);
-    if (d.dbg) {
+    if (d.dbg && !probe_tail) {
         --probe_left;
         (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h((size_t)nwg * 5);
-        (void)hipMemcpy(h.data(), dbg, (size_t)nwg * 40, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> h((size_t)nwg * 7);
+        (void)hipMemcpy(h.data(), dbg, (size_t)nwg * 56, hipMemcpyDeviceToHost);
+        double ghz = 0; int nghz = 0;
+        for (unsigned i = 0; i < nwg; ++i) {
+            const unsigned long long c0 = h[(size_t)nwg * 5 + 2 * i], c1 = h[(size_t)nwg * 5 + 2 * i + 1];
+            if (c1 > c0 && h[4 * i + 3] > h[4 * i]) { ghz += (double)(c1 - c0) / (double)(h[4 * i + 3] - h[4 * i]) * 0.1; ++nghz; }
+        }
         unsigned long long t0 = ~0ull, t1 = 0;
         double a = 0, b = 0, c2 = 0; int n = 0;
         for (unsigned i = 0; i < nwg; ++i) {
@@ -1136,8 +1173,8 @@ hipError_t launch_node_prop(const float* w, const GraphBufs& g, int round, hipSt
         }
         const double span = (double)(t1 - t0) * ncu;
         if (n) fprintf(stderr, "[ag node probe] round %d: %d workgroups on %d CUs, span %.1f us; mean per workgroup: gather+loads %.1f us, Wb layer %.1f us, "
-                               "W2+W3 layers+stores %.1f us | CU time with 0/1/2 workgroups in chain: %.0f%% %.0f%% %.0f%%; in gather: %.0f%% %.0f%% %.0f%%\n",
-                       round, n, ncu, (t1 - t0) * 0.01, a / n * 0.01, b / n * 0.01, c2 / n * 0.01,
+                               "W2+W3 layers+stores %.1f us, in-kernel clock %.3f GHz | CU time with 0/1/2 workgroups in chain: %.0f%% %.0f%% %.0f%%; in gather: %.0f%% %.0f%% %.0f%%\n",
+                       round, n, ncu, (t1 - t0) * 0.01, a / n * 0.01, b / n * 0.01, c2 / n * 0.01, nghz ? ghz / nghz : 0.0,
                        100 * chain[0] / span, 100 * chain[1] / span, 100 * chain[2] / span, 100 * gath[0] / span, 100 * gath[1] / span, 100 * gath[2] / span);
     }
     return hipGetLastError();
