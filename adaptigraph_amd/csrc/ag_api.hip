@@ -221,7 +221,7 @@ size_t work_bytes(int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices
                   bool own_group, int N_o, int ell_stride) {
     const size_t rows = (size_t)Bc * N;
     size_t bytes = 16 * 256;
-    bytes += rows * (NODE_IN + F12 + (own_group ? n_inst : 0)) * 4 + 6 * rows * NFP * 4 + ((size_t)Bc * c_cap + 256) * NFP * 4;
+    bytes += rows * (NODE_IN + F15_PITCH + (own_group ? n_inst : 0)) * 4 + 6 * rows * NFP * 4 + ((size_t)Bc * c_cap + 256) * NFP * 4;
     if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 3) * 4 + 3 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
     if (roll) bytes += rows * 4 + 1024 + (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
                        (size_t)cls_rows(N_o, N - N_o, Bc) * (NODE_IN + 4 * NFP) * 4;
@@ -234,7 +234,7 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
     const size_t rows = (size_t)Bc * N;
     Slab& s = c->slab;
     w.g.node_in = s.take<float>(rows * NODE_IN);
-    w.g.feat12 = s.take<float>(rows * F12);
+    w.g.feat12 = s.take<float>(rows * F15_PITCH);            // pitch 12 (n_his 4) or 16 (n_his 5, forward path)
     w.g.group = own_group ? s.take<float>(rows * n_inst) : nullptr;
     w.g.eff = s.take<float>(rows * NFP);
     w.g.P = s.take<float>(rows * NFP);
@@ -321,7 +321,7 @@ int run_model(ag_ctx* c, const GraphBufs& g, float* pred_pos, float* pred_motion
 int compute_self_rows(ag_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->d_cself) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_cself), 256 * NFP * 4));
-    struct Mini { float node_in[2 * NODE_IN]; float feat12[2 * F12]; float group[2]; int recv[2]; int send[2]; int n_edges; int pad; } h{};
+    struct Mini { float node_in[2 * NODE_IN]; float feat12[2 * F15_PITCH]; float group[2]; int recv[2]; int send[2]; int n_edges; int pad; } h{};
     h.node_in[0] = 1.f; h.node_in[6] = 1.f;                         // object particle
     h.node_in[NODE_IN + 1] = 1.f; h.node_in[NODE_IN + 6] = 1.f;     // tool particle
     h.group[0] = 1.f;
@@ -330,6 +330,7 @@ int compute_self_rows(ag_ctx* c) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d), sizeof(Mini)));
     HIPCHK(c, hipMemcpy(d, &h, sizeof(Mini), hipMemcpyHostToDevice));
     GraphBufs g{};
+    g.n_his = c->dims.n_his;
     g.node_in = reinterpret_cast<float*>(d + offsetof(Mini, node_in));
     g.feat12 = reinterpret_cast<float*>(d + offsetof(Mini, feat12));
     g.group = reinterpret_cast<float*>(d + offsetof(Mini, group));
@@ -367,9 +368,10 @@ int ag_ctx_create(int32_t device_id, const ag_dims* dims, ag_ctx** out) {
     ag_ctx* c = new ag_ctx();
     c->device = device_id; c->dims = *dims;
     *out = c;   // returned even on failure so the caller can read ag_last_error, then destroy
-    if (dims->nf != NF || dims->n_his != N_HIS || dims->in_dim != IN_DIM || dims->rel_dim != REL_DIM)
-        return fail(c, AG_ERR_UNSUPPORTED, "kernels are built for nf=150, n_his=4, in_dim=6, rel_dim=17 (got %d,%d,%d,%d)",
-                    dims->nf, dims->n_his, dims->in_dim, dims->rel_dim);
+    const bool his_ok = (dims->n_his == 4 || dims->n_his == N_HIS_MAX) && dims->rel_dim == 5 + 3 * dims->n_his;
+    if (dims->nf != NF || !his_ok || dims->in_dim != IN_DIM)
+        return fail(c, AG_ERR_UNSUPPORTED, "kernels are built for nf=150, in_dim=6 and n_his=4 (rel_dim 17) or n_his=5 "
+                    "(rel_dim 20, forward only) - got nf %d, n_his %d, in_dim %d, rel_dim %d", dims->nf, dims->n_his, dims->in_dim, dims->rel_dim);
     if (dims->pstep < 1) return fail(c, AG_ERR_INVALID, "pstep must be >= 1");
     HIPCHK(c, hipSetDevice(device_id));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_w), (size_t)WeightLayout::TOTAL * 4));
@@ -401,6 +403,7 @@ int ag_ctx_set_precision(ag_ctx* c, int32_t mode) {
     if (!c) return AG_ERR_INVALID;
     if (mode != 0 && mode != 1) return fail(c, AG_ERR_INVALID, "precision mode must be 0 (fp32) or 1 (bf16x3)");
     if (mode == c->precision) return AG_OK;
+    if (mode == 1 && c->dims.n_his != 4) return fail(c, AG_ERR_UNSUPPORTED, "the bf16x3 chains are built for n_his=4");
     c->precision = mode;
     return c->have_w ? compute_self_rows(c) : AG_OK;
 }
@@ -422,7 +425,7 @@ int ag_ctx_load_weights(ag_ctx* c, const float* const* t, int32_t n) {
     pack_first(b + WL::N_L1, t[0], IN_DIM, t[1], NODE_L1_CHUNKS);
     pack_layer(b + WL::N_L2, t[2], NF, 0, NF, NF, t[3], 5);
     pack_layer(b + WL::N_L3, t[4], NF, 0, NF, NF, t[5], 5);
-    pack_first(b + WL::E_L1, t[6], REL_DIM, t[7], EDGE_L1_CHUNKS);
+    pack_first(b + WL::E_L1, t[6], c->dims.rel_dim, t[7], EDGE_L1_CHUNKS);
     pack_layer(b + WL::E_L2, t[8], NF, 0, NF, NF, t[9], 5);
     pack_layer(b + WL::E_L3, t[10], NF, 0, NF, NF, t[11], 5);
     // particle propagator W_pp = [Wa | Wb] (150 x 300), bias with Wa
@@ -438,8 +441,8 @@ int ag_ctx_load_weights(ag_ctx* c, const float* const* t, int32_t n) {
     pack_layer(b + WL::P_P2, t[20], NF, 0, 3, NF, t[21], 1);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(c->d_w, b, blob.size() * 4, hipMemcpyHostToDevice));
-    // bf16x3 image (opt-in precision mode, ag_ctx_set_precision)
-    {
+    // bf16x3 image (opt-in precision mode, ag_ctx_set_precision; n_his = 4 models only)
+    if (c->dims.n_his == 4) {
         std::vector<uint16_t> img((size_t)B3_PHASES * B3_PHASE_BYTES / 2, 0);
         auto ph = [&](int phase) { return img.data() + (size_t)phase * B3_PHASE_BYTES / 2; };
         // phase indices = WLB in ag_mlp.hip
@@ -580,13 +583,13 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
     for (int b0 = 0; b0 < B; b0 += Bc) {
         const int nb = std::min(Bc, B - b0);
         GraphBufs g = w.g;
-        g.B = nb; g.n_p = n_p;
+        g.B = nb; g.n_p = n_p; g.n_his = c->dims.n_his;
         g.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
         g.group = const_cast<float*>(d_group) + (size_t)b0 * N * n_inst;
         g.recv = d_recv + (size_t)b0 * edge_cap; g.send = d_send + (size_t)b0 * edge_cap;
         g.row_ptr = d_row_ptr + (size_t)b0 * (N + 1); g.n_edges = n_eff + b0; g.n_guard = n_eff + b0;
         { Scoped p(c, FAM_PREP);
-          HIPCHK(c, launch_prep(d_state + (size_t)b0 * N_HIS * N * 3, d_attrs + (size_t)b0 * N * 2,
+          HIPCHK(c, launch_prep(d_state + (size_t)b0 * c->dims.n_his * N * 3, d_attrs + (size_t)b0 * N * 2,
                                 d_action + (size_t)b0 * N * 3, d_phys + (size_t)b0 * N, g, st)); }
         rc = run_model(c, g, d_pred_pos + (size_t)b0 * n_p * 3, d_pred_motion + (size_t)b0 * n_p * 3, st);
         if (rc) return rc;
@@ -609,6 +612,8 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         return fail(c, AG_ERR_INVALID, "ag_rollout: bad sizes B=%d H=%d N_o=%d M=%d max_nR=%d", p->B, p->H, p->N_o, p->M, p->max_nR);
     if (p->y_mode != 0 && p->y_mode != 1) return fail(c, AG_ERR_INVALID, "y_mode must be 0 or 1");
     if (p->y_mode == 1 && p->H != 1) return fail(c, AG_ERR_INVALID, "masked rollout has a single look-ahead step");
+    if (c->dims.n_his != N_HIS)
+        return fail(c, AG_ERR_UNSUPPORTED, "the rollout driver is built for n_his=4 (every planner task config); this model has n_his=%d", c->dims.n_his);
     const int N = p->N_o + p->M;
     int rc = check_topk(c, N, p->topk);
     if (rc) return rc;

@@ -9,10 +9,15 @@ namespace ag {
 constexpr int NF = 150;        // real feature width of every hidden layer
 constexpr int NFP = 160;       // row pitch of every activation buffer (5 MFMA tiles of 32)
 constexpr int ONE_F = 150;     // slot that carries the constant 1.0 (bias rides in weight column 150)
-constexpr int N_HIS = 4;
+constexpr int N_HIS = 4;       // history frames of the ROLLOUT path (every planner task config: n_his 4)
 constexpr int IN_DIM = 6;      // [attr_obj, attr_tool, phys, act_x, act_y, act_z]
 constexpr int REL_DIM = 17;    // [attr_r(2), attr_s(2), group_diff, (res0,res1,res2,cur)_r - (...)_s]
 constexpr int F12 = 3 * N_HIS; // per-particle history feature row
+// The forward path (ag_forward) also serves the softbody model variant: n_his = 5, rel_input_dim = 20
+// (src/config/dynamics/softbody.yaml:29).  Its feature rows are 15 floats at a 16-float pitch.
+constexpr int N_HIS_MAX = 5;
+constexpr int F15_PITCH = 16;
+inline int feat_pitch(int n_his) { return n_his == 5 ? F15_PITCH : F12; }
 constexpr int NODE_IN = 8;     // node input row: 6 features, 1.0, pad
 
 // ---- packed weight geometry ----------------------------------------------------------------------------
@@ -143,6 +148,7 @@ struct GraphBufs {
     // particle index) is computed ONCE, on the rows of a phantom candidate B (all particles masked out, no tools, no
     // edges) appended to the list; k_roll_update applies it to the masked-out rows of every real candidate.
     const int* rowlist; const int* n_rows; // (B*N + N_o,), (1,) device; null = all rows
+    int n_his;                             // 4 (0 = 4), or 5 on the forward path (feature rows then have pitch F15_PITCH)
 };
 constexpr int B3_PHASE_BYTES = 2 * 5 * 3 * 64 * 16;   // 30,720
 constexpr int B3_PHASES = 58;
@@ -158,7 +164,7 @@ hipError_t launch_node_final(const float* wblob, const GraphBufs& g, int round, 
 hipError_t launch_edge_guard(const int* n_edges, int B, int edge_cap, int* n_eff, int* overflow, hipStream_t st);
 // model-input preparation for ag_forward: state (B,n_his,N,3) etc. -> node_in, feat12
 hipError_t launch_prep(const float* state, const float* attrs, const float* action, const float* phys,
-                       const GraphBufs& g, hipStream_t st);
+                       const GraphBufs& g, hipStream_t st);   // state has g.n_his frames
 
 struct RollBufs {
     float* hist;        // (B, N_HIS, N, 3)

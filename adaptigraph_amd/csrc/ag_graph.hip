@@ -31,22 +31,26 @@ struct PrepDev {
     const float* state; const float* attrs; const float* action; const float* phys;
     float* node_in; float* feat12; int B, N;
 };
+template <int NH>
 __global__ void k_prep(PrepDev p) {
+    constexpr int FP = NH == 5 ? F15_PITCH : F12;
     const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= (long)p.B * p.N) return;
     const int b = (int)(row / p.N), i = (int)(row - (long)b * p.N);
-    float s[N_HIS][3];
+    float s[NH][3];
 #pragma unroll
-    for (int h = 0; h < N_HIS; ++h)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s[h][c] = p.state[(((long)b * N_HIS + h) * p.N + i) * 3 + c];
-    float* f = p.feat12 + row * F12;
+        for (int c = 0; c < 3; ++c) s[h][c] = p.state[(((long)b * NH + h) * p.N + i) * 3 + c];
+    float* f = p.feat12 + row * FP;
 #pragma unroll
-    for (int h = 0; h < N_HIS - 1; ++h)
+    for (int h = 0; h < NH - 1; ++h)
 #pragma unroll
         for (int c = 0; c < 3; ++c) f[3 * h + c] = s[h + 1][c] - s[h][c];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) f[3 * (N_HIS - 1) + c] = s[N_HIS - 1][c];
+    for (int c = 0; c < 3; ++c) f[3 * (NH - 1) + c] = s[NH - 1][c];
+#pragma unroll
+    for (int k = 3 * NH; k < FP; ++k) f[k] = 0.0f;
     float* n = p.node_in + row * NODE_IN;
     n[0] = p.attrs[row * 2 + 0]; n[1] = p.attrs[row * 2 + 1]; n[2] = p.phys[row];
     n[3] = p.action[row * 3 + 0]; n[4] = p.action[row * 3 + 1]; n[5] = p.action[row * 3 + 2];
@@ -56,7 +60,8 @@ hipError_t launch_prep(const float* state, const float* attrs, const float* acti
                        const GraphBufs& g, hipStream_t st) {
     PrepDev p{state, attrs, action, phys, g.node_in, g.feat12, g.B, g.N};
     const long rows = (long)g.B * g.N;
-    hipLaunchKernelGGL(k_prep, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
+    if (g.n_his == 5) hipLaunchKernelGGL(k_prep<5>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(k_prep<4>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 

@@ -280,6 +280,7 @@ struct GDev {
     // particles and tools, plus one phantom candidate that stands for every masked-out particle (GraphBufs) - instead of
     // all B*N rows; rowlist[slot] = dense row b*N + i, *n_rows = number of slots.  Null: every dense row, in order.
     const int* rowlist; const int* n_rows;
+    int f_pitch, cur_off;                     // feature-row pitch and offset of the current position in it (n_his 4: 12, 9)
     unsigned long long* dbg;   // diagnostic build of the clock probe only: 4 stamps per workgroup, never read by kernels
 };
 
@@ -516,7 +517,10 @@ __device__ __forceinline__ void stagger_second_workgroup(const GDev& g) {
 
 // ------------------------------------------------------------------------------------------------ edge chain
 // rel_inputs (17) -> Encoder(17,150,150) -> W1*enc + b_rp  => C      (model.py:249-282, 303, 317-318 first block)
+// NH = history frames: 4 (rel_inputs 17) or, on the forward path only, 5 (rel_inputs 20: softbody.yaml)
+template <int NH>
 __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
+    constexpr int FP = NH == 5 ? F15_PITCH : F12, NQ = FP / 4, RD = 5 + 3 * NH;
     __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* stg = lds + 2 * BUF_FLOATS + wave * STG_FLOATS;
@@ -550,17 +554,17 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
         float gd = 0.0f;
         for (int k = 0; k < g.n_inst; ++k) gd += fabsf(g.group[pr * g.n_inst + k] - g.group[ps * g.n_inst + k]);
         f[4] = gd;                                                               // model.py:264-267
-        const f32x4* fr = reinterpret_cast<const f32x4*>(g.feat12 + pr * F12);
-        const f32x4* fs = reinterpret_cast<const f32x4*>(g.feat12 + ps * F12);
+        const f32x4* fr = reinterpret_cast<const f32x4*>(g.feat12 + pr * FP);
+        const f32x4* fs = reinterpret_cast<const f32x4*>(g.feat12 + ps * FP);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const f32x4 a = fr[q], c = fs[q];
             f[5 + 4 * q + 0] = a[0] - c[0]; f[5 + 4 * q + 1] = a[1] - c[1];     // pos_r - pos_s       model.py:277-279
             f[5 + 4 * q + 2] = a[2] - c[2]; f[5 + 4 * q + 3] = a[3] - c[3];
         }
-        f[17] = 1.0f;
+        f[RD] = 1.0f;                                                            // bias slot behind the RD relation inputs
 #pragma unroll
-        for (int k = 18; k < 8 * EDGE_L1_CHUNKS; ++k) f[k] = 0.0f;
+        for (int k = RD + 1; k < 8 * EDGE_L1_CHUNKS; ++k) f[k] = 0.0f;
     }
     Act x, y;
     zero(y);
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
         // motion xyz = output features 0,1,2 = registers 0,1,2 of lanes 0..31
         const int b = pb, i = pi;
         if (valid && lane < 32 && i < g.n_p) {
-            const float* cur = g.feat12 + rowc * F12 + 9;    // state[:, -1]  (model.py:338)
+            const float* cur = g.feat12 + rowc * g.f_pitch + g.cur_off;    // state[:, -1]  (model.py:338)
             const long o = ((long)b * g.n_p + i) * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -1026,6 +1030,7 @@ static GDev to_dev(const float* w, const GraphBufs& g) {
     d.Uin = nullptr; d.Vin = nullptr; d.deg = g.deg; d.ell_stride = g.ell_stride; d.dedupe = g.c_self ? 1 : 0;
     d.self_row = (unsigned)g.self_row; d.n_guard = g.n_guard;
     d.rowlist = g.rowlist; d.n_rows = g.n_rows;
+    d.f_pitch = feat_pitch(g.n_his); d.cur_off = g.n_his == 5 ? 12 : 9;
     // AG_STAGGER_US: offset between the two workgroups of a CU in the fused propagate chains (0 = off)
     static const int stagger_us = getenv("AG_STAGGER_US") ? atoi(getenv("AG_STAGGER_US")) : 30;
     d.stagger_ticks = stagger_us * 100; d.first_wave = 512;
@@ -1051,7 +1056,8 @@ hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
         d.dbg = dbg;
     }
     if (d.wb3) hipLaunchKernelGGL(k_edge_enc_b3, dim3((unsigned)(rows / WGB_ROWS)), dim3(WGB), 0, st, d);
-    else hipLaunchKernelGGL(k_edge_enc, dim3(nwg), dim3(WG), 0, st, d);
+    else if (g.n_his == 5) hipLaunchKernelGGL(k_edge_enc<5>, dim3(nwg), dim3(WG), 0, st, d);
+    else hipLaunchKernelGGL(k_edge_enc<4>, dim3(nwg), dim3(WG), 0, st, d);
     if (probe_left > 0) {
         --probe_left;
         (void)hipStreamSynchronize(st);

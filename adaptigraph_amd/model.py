@@ -55,12 +55,12 @@ class DynamicsPredictor(nn.Module):
                        model_config["attr_dim"] != 2 or model_config["action_dim"] != 3 or material_dim != 1 or
                        model_config["rel_attr_dim"] != 2 or model_config["rel_group_dim"] != 1 or
                        model_config["rel_distance_dim"] != 3)
-        if unsupported or input_dim != 6 or rel_input_dim != 17 or self.n_his != 4 or \
+        if unsupported or input_dim != 6 or self.n_his not in (4, 5) or rel_input_dim != 5 + 3 * self.n_his or \
                 not (self.nf_particle == self.nf_relation == self.nf_effect == 150):
             raise NotImplementedError(
-                "the HIP kernels are built for input_dim 6, rel_input_dim 17, n_his 4, nf 150 - the configuration of "
-                "config/dynamics/{rope,granular,cloth}.yaml; softbody.yaml (n_his 5, rel_input_dim 20) is not "
-                f"implemented (got {input_dim}, {rel_input_dim}, {self.n_his}, {self.nf_effect})")
+                "the HIP kernels are built for input_dim 6, nf 150 and n_his 4 (rel_input_dim 17: config/dynamics/"
+                "{rope,granular,cloth,...}.yaml) or n_his 5 (rel_input_dim 20: softbody.yaml, forward() only) - got "
+                f"{input_dim}, {self.nf_effect}, {self.n_his}, {rel_input_dim}")
         self.input_dim, self.rel_input_dim = input_dim, rel_input_dim
 
         nf = self.nf_effect
@@ -94,7 +94,8 @@ class DynamicsPredictor(nn.Module):
     def engine(self, device=None):
         dev = _require_gpu(device if device is not None else self.device)
         if self._engine is None or self._engine.device != dev:
-            self._engine = Engine(dev, pstep=self.model_config["pstep"], motion_clamp=float(self.motion_clamp))
+            self._engine = Engine(dev, pstep=self.model_config["pstep"], n_his=self.n_his, rel_dim=self.rel_input_dim,
+                                  motion_clamp=float(self.motion_clamp))
             self._uploaded_key = None
             if self._precision is not None:
                 self._engine.set_precision(self._precision)

@@ -46,14 +46,16 @@ extern "C" {
 typedef struct ag_ctx ag_ctx;
 
 /* Model dimensions = what DynamicsPredictor.__init__ derives from model_config
- * (src/dynamics/gnn/model.py:78-123).  Every shipped config has nf=150, n_his=4,
- * in_dim=6 (attr 2 + physics 1 + action 3), rel_dim=17 (2*attr 2 + group 1 + 3*n_his). */
+ * (src/dynamics/gnn/model.py:78-123).  Every shipped config has nf=150, in_dim=6 (attr 2 + physics 1 + action 3) and
+ * rel_dim = 2*attr 2 + group 1 + 3*n_his: 17 with n_his=4 (rope, granular, cloth, ... and every planner task config),
+ * 20 with n_his=5 (config/dynamics/softbody.yaml:29).  n_his=5 is served by ag_forward only (the eval-rollout path's
+ * model(**graph), rollout.py:112); ag_rollout and the bf16x3 arithmetic return AG_ERR_UNSUPPORTED for it. */
 typedef struct ag_dims {
     int32_t nf;            /* nf_particle == nf_relation == nf_effect; kernels are built for 150 */
-    int32_t n_his;         /* history frames; kernels are built for 4                            */
+    int32_t n_his;         /* history frames: 4, or 5 (forward only)                             */
     int32_t pstep;         /* message-passing rounds (3; softbody.yaml uses 4)                   */
     int32_t in_dim;        /* particle-encoder input width, must be 6                            */
-    int32_t rel_dim;       /* relation-encoder input width, must be 17                           */
+    int32_t rel_dim;       /* relation-encoder input width, must be 5 + 3*n_his                  */
     float motion_clamp;    /* model.py:86, 100.0                                                 */
 } ag_dims;
 
@@ -137,7 +139,7 @@ int ag_edges_apply_tool_rule(ag_ctx* ctx, void* stream, const float* d_pos, cons
                              int32_t* d_row_ptr_out, int32_t* d_n_out);
 
 /* Replaces DynamicsPredictor.forward (src/dynamics/gnn/model.py:130-342) on index-list graphs.
- *   d_state (B,n_his,N,3); d_attrs (B,N,2); d_action (B,N,3); d_phys (B,N) physics parameter per particle, zero
+ *   d_state (B,n_his,N,3) with the ctx's n_his; d_attrs (B,N,2); d_action (B,N,3); d_phys (B,N) physics parameter per particle, zero
  *   for the trailing N-n_p tool particles (model.py:206-207); d_group (B,N,n_inst) = [p_instance ; 0] (model.py:264);
  *   edges as produced by ag_build_edges (must be sorted by receiver; row_ptr consistent).
  * Outputs d_pred_pos, d_pred_motion (B,n_p,3) (model.py:335-338).

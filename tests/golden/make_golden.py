@@ -433,7 +433,7 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5"} & set(sys.argv)):
     main()
 
 # dynamics_masked for the other two materials: gripper offset + connect_tools_all (cloth) and the 5-point pusher
@@ -766,3 +766,52 @@ def gen_single_rules(name):
 
 if __name__ == "__main__" and "--single-rules" in sys.argv:
     gen_single_rules("edges_single_rules")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The softbody model variant: n_his = 5 (rest state kept in the history), pstep = 4, rel_input_dim = 20
+# (src/config/dynamics/softbody.yaml:29,126).  One model(**graph) call - the eval-rollout path's forward (rollout.py:112).
+def gen_forward_nhis5_case(name, refs):
+    DynamicsPredictor, construct, _, _ = refs
+    rng = np.random.default_rng(15)
+    with open(f"{REF}/config/dynamics/softbody.yaml") as f:
+        dyn = yaml.safe_load(f)
+    assert dyn["dataset_config"]["n_his"] == 5 and dyn["model_config"]["pstep"] == 4
+    model = make_model(DynamicsPredictor, dyn, 15)
+    assert model.state_dict()["relation_encoder.model.0.weight"].shape == (150, 20)
+    B, N_o, M, n_his = 2, 120, 5, 5
+    N = N_o + M
+    base = grid_cloud(11, 0.12, 0.02, rng)[:N_o]
+    state = np.zeros((B, n_his, N, 3), np.float32)
+    for b in range(B):
+        for h in range(n_his):
+            state[b, h, :N_o] = base + rng.normal(0, 0.01, base.shape).astype(np.float32) * (h + 1)
+            state[b, h, N_o:] = base[50 + b] + np.float32([0.05, 0.0, 0.03]) * np.arange(M)[:, None] + 0.01 * h
+    attrs = np.zeros((B, N, 2), np.float32)
+    attrs[:, :N_o, 0] = 1
+    attrs[:, N_o:, 1] = 1
+    action = np.zeros((B, N, 3), np.float32)
+    action[:, N_o:] = rng.normal(0, 0.1, (B, 1, 3)).astype(np.float32)
+    p_instance = np.ones((B, N_o, 1), np.float32)
+    phys = rng.uniform(0.1, 0.9, (B, 1)).astype(np.float32)
+    mask = np.ones((B, N), bool)
+    tool = np.zeros((B, N), bool)
+    tool[:, N_o:] = True
+    ts = torch.from_numpy(state)
+    assert_no_topk_boundary_tie(ts[:, -1], torch.from_numpy(mask), torch.from_numpy(tool), 0.4, 20)
+    Rr, Rs = construct(ts[:, -1], 0.4, torch.from_numpy(mask), torch.from_numpy(tool), topk=20, connect_tools_all=False)
+    graph = dict(state=ts, attrs=torch.from_numpy(attrs), Rr=Rr, Rs=Rs, p_instance=torch.from_numpy(p_instance),
+                 action=torch.from_numpy(action), softbody_physics_param=torch.from_numpy(phys))
+    with torch.no_grad():
+        pred_pos, pred_motion = quiet(model, **graph)
+    store = weights_npz(model)
+    store.update(state=state, attrs=attrs, action=action, p_instance=p_instance, physics_param=phys,
+                 pred_pos=pred_pos.numpy(), pred_motion=pred_motion.numpy(), pstep=np.int32(4), n_his=np.int32(5))
+    pack_edges("", edges_from_R(Rr, Rs), store)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: E={[len(r) for r, _ in edges_from_R(Rr, Rs)]} -> {os.path.getsize(path)/1e6:.2f} MB")
+
+
+if __name__ == "__main__" and "--nhis5" in sys.argv:
+    gen_forward_nhis5_case("forward_softbody_nhis5", import_reference())

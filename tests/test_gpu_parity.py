@@ -30,7 +30,7 @@ def ag():
 
 
 def _cfg(material, pstep=3):
-    phys = {"rope": "particle_radius", "granular": "granular_scale", "cloth": "sf"}[material]
+    phys = {"rope": "particle_radius", "granular": "granular_scale", "cloth": "sf", "softbody": "stiffness"}[material]
     model_config = dict(verbose=False, nf_particle=150, nf_relation=150, nf_effect=150, nf_physics=10, attr_dim=2,
                         state_dim=0, offset_dim=0, action_dim=3, density_dim=0, pstep=pstep, sequence_len=4,
                         rel_particle_dim=0, rel_attr_dim=2, rel_group_dim=1, rel_distance_dim=3, rel_density_dim=0)
@@ -315,3 +315,34 @@ def test_dynamics_repeat_zero_vs_reference_golden(ag, dev):
     assert np.all(got[0, 0] == 0) and np.all(got[1, 1] == 0)
     assert torch.equal(out["action_seqs"].cpu(), torch.from_numpy(g["action_seqs"]))
     assert np.abs(got - g["state_seqs"]).max() <= POS_TOL
+
+
+def test_forward_softbody_variant_nhis5_vs_reference_golden(ag, dev):
+    """config/dynamics/softbody.yaml: n_his = 5 (rel_input_dim 20), pstep = 4 - the eval-rollout path's model(**graph).
+    The rollout driver (planner path, n_his 4 in every task config) refuses such a model loudly."""
+    g = load_golden("forward_softbody_nhis5")
+    mc, mat, ds = _cfg("softbody", int(g["pstep"]))
+    ds = dict(ds, n_his=5)
+    m = ag.DynamicsPredictor(mc, mat, ds, dev)
+    m.load_state_dict({k[3:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith("w::")})
+    edges = split_edges(g, "")
+    B, N = g["attrs"].shape[:2]
+    E = max(len(r) for r, _ in edges)
+    Rr, Rs = torch.zeros((B, E, N)), torch.zeros((B, E, N))
+    for b, (r, s) in enumerate(edges):
+        Rr[b, torch.arange(len(r)), torch.from_numpy(r).long()] = 1
+        Rs[b, torch.arange(len(s)), torch.from_numpy(s).long()] = 1
+    kw = dict(state=torch.from_numpy(g["state"]).to(dev), attrs=torch.from_numpy(g["attrs"]).to(dev),
+              p_instance=torch.from_numpy(g["p_instance"]).to(dev), action=torch.from_numpy(g["action"]).to(dev),
+              softbody_physics_param=torch.from_numpy(g["physics_param"]).to(dev))
+    pos, mot = m(Rr=Rr.to(dev), Rs=Rs.to(dev), **kw)
+    assert np.abs(pos.cpu().numpy() - g["pred_pos"]).max() <= POS_TOL
+    assert np.abs(mot.cpu().numpy() - g["pred_motion"]).max() <= POS_TOL
+    with pytest.raises(NotImplementedError, match="n_his"):
+        m.set_precision("bf16x3")
+    m._precision = None
+    task = dict(adj_thresh=0.4, topk=20, connect_tools_all=False, sim_real_ratio=10, push_length=0.2, gripper_enable=False,
+                max_n=1, max_nR=9000, n_his=5, eef_num=1, material="softbody", pusher_points=[[0, 0, 0.1]],
+                material_dims={"softbody": 1}, material_indices={"softbody": 0})
+    with pytest.raises(NotImplementedError, match="n_his"):
+        ag.dynamics(torch.zeros((10, 3), device=dev), torch.ones((1, 1, 4), device=dev), m, dev, _ppm(task, "softbody"))

@@ -179,3 +179,15 @@ def test_dynamics_repeat_zero_vs_reference():
     assert np.array_equal(out["action_seqs"], g["action_seqs"])
     assert np.all(g["state_seqs"][0, 0] == 0) and np.all(g["state_seqs"][1, 1] == 0)
     assert np.abs(out["state_seqs"] - g["state_seqs"]).max() < POS_TOL
+
+
+def test_forward_softbody_variant_nhis5_pstep4():
+    """The n_his = 5 / rel_input_dim = 20 / pstep = 4 model of config/dynamics/softbody.yaml (forward only)."""
+    g = load_golden("forward_softbody_nhis5")
+    W = O.weights_from_npz(g)
+    assert W["relation_encoder.model.0.weight"].shape == (150, 20) and g["state"].shape[1] == 5
+    edges = split_edges(g, "")
+    pos, mot = O.model_forward(W, g["state"], g["attrs"], edges, g["p_instance"], g["action"],
+                               g["physics_param"], int(g["pstep"]))
+    assert np.abs(pos - g["pred_pos"]).max() < POS_TOL
+    assert np.abs(mot - g["pred_motion"]).max() < POS_TOL
