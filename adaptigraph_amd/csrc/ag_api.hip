@@ -15,6 +15,11 @@
 namespace ag {
 size_t edge_build_max_particles();
 int edge_ell_stride(int N, int topk);
+size_t lat_weights_floats();
+size_t lat_weights_offset(int which);
+hipError_t launch_edge_enc_lat(const float* wl, const GraphBufs& g, hipStream_t st);
+hipError_t launch_node_prop_lat(const float* wl, const GraphBufs& g, int round, bool last, float clamp, float* pred_pos,
+                                float* pred_motion, hipStream_t st);
 }
 using namespace ag;
 
@@ -44,6 +49,7 @@ struct ag_ctx {
     std::string err;
     float* d_w = nullptr;
     float* d_wb3 = nullptr;      // bf16x3 weight image (58 phases of 30,720 B)
+    float* d_wlat = nullptr;     // weight image of the latency-mode chains (ag_lat.hip), n_his = 4 models only
     int precision = 0;           // 0: exact fp32 MFMA (default), 1: bf16x3 split on the bf16 matrix pipe
     bool have_w = false;
     Slab slab;
@@ -141,6 +147,49 @@ void pack_first(float* dst, const float* W, int in_dim, const float* bias, int n
                         else if (k == in_dim) v = bias[m];
                     }
                     dst[((size_t)(q * 5 + mb) * 64 + lane) * 4 + e] = v;
+                }
+}
+
+// ---- latency-mode chains (ag_lat.hip): A-operand image of v_mfma_f32_16x16x4_f32, [chunk of 4 k-steps][tile][lane][4].
+// Register r of tile T in lane group g stands for feature 16T + 8(r>>1) + 4(g&1) + 2(r&1) + (g>>1): the k sequence of the
+// 32-row chains (slot_of) cut into steps of four, so that both kernel families round identically.  >= 152: dead slot.
+int feat_lat(int T, int g, int r) {
+    const int f = 16 * T + 8 * (r >> 1) + 4 * (g & 1) + 2 * (r & 1) + (g >> 1);
+    return f < 152 ? f : -1;
+}
+void pack_layer_lat(float* dst, const float* W, int ld, int col0, int out_dim, int in_dim, const float* bias, bool head) {
+    const int ntile = head ? 1 : 10;
+    for (int c = 0; c < 10; ++c)
+        for (int mt = 0; mt < ntile; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int s = 4 * c + e;
+                    float v = 0.f;
+                    if (s < 38) {
+                        const int T = s < 36 ? s / 4 : 9, r = s < 36 ? s % 4 : s - 36;
+                        const int k = feat_lat(T, lane >> 4, r), i = lane & 15;
+                        // D row 4g + r of an output tile = A row i: the head keeps its 3 outputs in rows 0..2
+                        const int m = head ? i : feat_lat(mt, i >> 2, i & 3);
+                        if (m >= 0 && m < out_dim && k >= 0) {
+                            if (k < in_dim) v = W[(size_t)m * ld + col0 + k];
+                            else if (k == ONE_F && bias) v = bias[m];
+                        }
+                    }
+                    dst[((size_t)(c * ntile + mt) * 64 + lane) * 4 + e] = v;
+                }
+}
+void pack_first_lat(float* dst, const float* W, int in_dim, const float* bias, int nchunks) {
+    for (int c = 0; c < nchunks; ++c)
+        for (int mt = 0; mt < 10; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * (4 * c + e) + (lane >> 4), i = lane & 15, m = feat_lat(mt, i >> 2, i & 3);
+                    float v = 0.f;
+                    if (m >= 0 && m < NF) {
+                        if (k < in_dim) v = W[(size_t)m * in_dim + k];
+                        else if (k == in_dim) v = bias[m];
+                    }
+                    dst[((size_t)(c * 10 + mt) * 64 + lane) * 4 + e] = v;
                 }
 }
 
@@ -308,10 +357,26 @@ int auto_chunk(const ag_ctx* c, int B, int N) {
 // encoder outputs already sit in the class table (encoded at look-ahead-step start) and k_node_enc is skipped.
 int run_model(ag_ctx* c, const GraphBufs& g, float* pred_pos, float* pred_motion, hipStream_t st) {
     if (!g.cls_on) { Scoped p(c, FAM_NODE_ENC); HIPCHK(c, launch_node_enc(c->d_w, g, 0, (long)g.B * g.N, st)); }
-    { Scoped p(c, FAM_EDGE_ENC); HIPCHK(c, launch_edge_enc(c->d_w, g, st)); }
+    // Small launches are latency-bound: below one chip-filling round of 128-row workgroups the latency-mode chains take
+    // over (ag_lat.hip: 32-row workgroups, every layer split over the four wavefronts; bit-identical results).
+    // AG_LATENCY: 0 never, 1 always, unset = by size.
+    const int lat_env = getenv("AG_LATENCY") ? atoi(getenv("AG_LATENCY")) : -1;   // read per call (tests toggle it)
+    const bool lat_ok = c->d_wlat && !g.wb3 && g.n_his != 5;
+    const long edge_wgs = (long)g.B * g.c_cap / 128, node_wgs = ((long)g.B * g.N + 127) / 128;
+    // (thresholds in 128-row workgroups of the throughput kernels: a latency workgroup reads its weight fragments from L2
+    // itself - 200 KB per layer - so beyond about one latency workgroup per CU the L2 traffic eats the gain: rope 64 x 301
+    // rows = 151 workgroups runs the same 71 us either way, one rope graph 66 -> 31 us)
+    const bool lat_edge = lat_ok && (lat_env >= 0 ? lat_env == 1 : edge_wgs <= 128);
+    const bool lat_node = lat_ok && (lat_env >= 0 ? lat_env == 1 : node_wgs <= 64);
+    { Scoped p(c, FAM_EDGE_ENC);
+      if (lat_edge) HIPCHK(c, launch_edge_enc_lat(c->d_wlat, g, st));
+      else HIPCHK(c, launch_edge_enc(c->d_w, g, st)); }
     for (int ps = 0; ps < c->dims.pstep; ++ps) {
-        if (ps + 1 < c->dims.pstep) { Scoped p(c, FAM_NODE_PROP); HIPCHK(c, launch_node_prop(c->d_w, g, ps, st)); }
-        else { Scoped p(c, FAM_NODE_FINAL); HIPCHK(c, launch_node_final(c->d_w, g, ps, c->dims.motion_clamp, pred_pos, pred_motion, st)); }
+        const bool last = ps + 1 == c->dims.pstep;
+        Scoped p(c, last ? FAM_NODE_FINAL : FAM_NODE_PROP);
+        if (lat_node) HIPCHK(c, launch_node_prop_lat(c->d_wlat, g, ps, last, c->dims.motion_clamp, pred_pos, pred_motion, st));
+        else if (!last) HIPCHK(c, launch_node_prop(c->d_w, g, ps, st));
+        else HIPCHK(c, launch_node_final(c->d_w, g, ps, c->dims.motion_clamp, pred_pos, pred_motion, st));
     }
     return AG_OK;
 }
@@ -391,6 +456,7 @@ int ag_ctx_destroy(ag_ctx* c) {
     }
     if (c->d_w) (void)hipFree(c->d_w);
     if (c->d_wb3) (void)hipFree(c->d_wb3);
+    if (c->d_wlat) (void)hipFree(c->d_wlat);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
     if (c->d_cself) (void)hipFree(c->d_cself);
     if (c->d_repeat) (void)hipFree(c->d_repeat);
@@ -462,6 +528,22 @@ int ag_ctx_load_weights(ag_ctx* c, const float* const* t, int32_t n) {
         pack_layer_b3(ph(57), t[20], NF, 0, 3, NF, t[21], 1);
         if (!c->d_wb3) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wb3), img.size() * 2));
         HIPCHK(c, hipMemcpy(c->d_wb3, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (c->dims.n_his == 4) {   // latency-mode image
+        std::vector<float> wl(lat_weights_floats(), 0.f);
+        float* L = wl.data();
+        pack_first_lat(L + lat_weights_offset(0), t[6], REL_DIM, t[7], 2);
+        pack_layer_lat(L + lat_weights_offset(1), t[8], NF, 0, NF, NF, t[9], false);
+        pack_layer_lat(L + lat_weights_offset(2), t[10], NF, 0, NF, NF, t[11], false);
+        pack_layer_lat(L + lat_weights_offset(3), t[14], 3 * NF, 0, NF, NF, t[15], false);        // W1 + b_rp
+        pack_layer_lat(L + lat_weights_offset(4), t[12], 2 * NF, NF, NF, NF, nullptr, false);     // Wb
+        pack_layer_lat(L + lat_weights_offset(5), t[14], 3 * NF, NF, NF, NF, nullptr, false);     // W2
+        pack_layer_lat(L + lat_weights_offset(6), t[14], 3 * NF, 2 * NF, NF, NF, nullptr, false); // W3
+        pack_layer_lat(L + lat_weights_offset(7), t[16], NF, 0, NF, NF, t[17], false);            // predictor 0
+        pack_layer_lat(L + lat_weights_offset(8), t[18], NF, 0, NF, NF, t[19], false);            // predictor 1
+        pack_layer_lat(L + lat_weights_offset(9), t[20], NF, 0, 3, NF, t[21], true);              // predictor 2 (3 outputs)
+        if (!c->d_wlat) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wlat), wl.size() * 4));
+        HIPCHK(c, hipMemcpy(c->d_wlat, wl.data(), wl.size() * 4, hipMemcpyHostToDevice));
     }
     c->have_w = true;
     return compute_self_rows(c);

@@ -625,3 +625,35 @@ def test_ragged_row_list_equals_dense_rows_bitwise(ag, O, dev, topk):
     assert torch.equal(chunked, dense)
     want = O.dynamics_masked(W, 3, state, mask, a, task)["state_seqs"]
     assert np.abs(ragged.cpu().numpy() - want).max() <= POS_TOL
+
+
+@pytest.mark.parametrize("material,cloud_fn,B", [
+    ("rope", lambda r: _rope(120, r), 3),
+    ("granular", lambda r: _grid(12, 0.12, 0.02, r), 2),
+    ("cloth", lambda r: _grid(14, 0.3, 0.02, r), 2),
+])
+def test_latency_kernels_equal_throughput_kernels_bitwise(ag, O, dev, material, cloud_fn, B):
+    """Small batches run the latency-mode chains (csrc/ag_lat.hip: 32-row workgroups, every layer split over four
+    wavefronts on v_mfma_f32_16x16x4_f32), large ones the throughput chains (32-row wavefronts, v_mfma_f32_32x32x2_f32).
+    Both feed the k's of every layer in the same order, so they must agree bit for bit - which is what keeps results
+    independent of batch size, chunking and sharding across the switch."""
+    import os
+    rng = np.random.default_rng(71)
+    task = _task(material)
+    W, m = _model(ag, O, material, 71, dev)
+    cloud = cloud_fn(rng)
+    a = torch.from_numpy(_actions(cloud, B, 2, [[2, 1], [3, 2], [1, 3]][:B], rng)).to(dev)
+    s0 = torch.from_numpy(cloud).to(dev)
+    out = {}
+    for mode in ("0", "1"):
+        os.environ["AG_LATENCY"] = mode
+        try:
+            out[mode] = ag.dynamics(s0, a, m, dev, _ppm(task, material))["state_seqs"]
+        finally:
+            del os.environ["AG_LATENCY"]
+    assert torch.isfinite(out["1"]).all()
+    assert torch.equal(out["0"], out["1"])
+    auto = ag.dynamics(s0, a, m, dev, _ppm(task, material))["state_seqs"]      # by size: latency mode here
+    assert torch.equal(auto, out["0"])
+    want = O.dynamics(W, 3, cloud, a.cpu().numpy(), task)["state_seqs"]
+    assert np.abs(auto.cpu().numpy() - want).max() <= POS_TOL
