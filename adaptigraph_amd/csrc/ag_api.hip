@@ -725,6 +725,12 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     const bool ell_full = ell_env && dedupe_env && k < N;
     const int edge_cap = (int)round_up((size_t)(ell_full ? bound : std::min<long>(bound, p->max_nR)), 256);
     int ns = std::max(1, std::min(c->n_streams, (int)ag_ctx::kMaxStreams));
+    {   // batches of eight or more full-size chunks run on four streams (two chunks each): the memory-bound phases of
+        // three chunks then hide under the MFMA-bound k_edge_enc of a fourth (1024 x 2026 cloth: 497.8 ms on two streams,
+        // 491.8 on three, 488.6 on four; with fewer chunks the streams would only cut them smaller)
+        const int full = auto_chunk(c, p->B, N);
+        if (c->n_streams == 2 && (p->B + full - 1) / full >= 8) ns = 4;
+    }
     if ((long)p->B * N < 65536) ns = 1;   // small batches are dispatch-bound: a second stream only doubles the launches
                                           // (rope 64 x 301: 10.8 ms on one stream, 12.9 ms on two)
     if (const char* e = getenv("AG_STREAMS")) ns = std::max(1, std::min(atoi(e), (int)ag_ctx::kMaxStreams));

@@ -107,7 +107,8 @@ __device__ __forceinline__ void mma_act(const float* wl, const Act& in, f32x16* 
 }
 
 // first layer: input features f[0 .. 8*NCH) held per lane; step s consumes (f[2s], f[2s+1]) on the two lane halves
-template <int NCH>
+// NST: k-steps that carry an input or the bias slot; later steps of the last chunk multiply zeros and are skipped
+template <int NCH, int NST = 4 * NCH>
 __device__ __forceinline__ void mma_feat(const float* wl, const float* f, f32x16* acc, int lane) {
     const bool hi = lane >= 32;
 #pragma unroll
@@ -118,6 +119,7 @@ __device__ __forceinline__ void mma_feat(const float* wl, const float* f, f32x16
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int s = 4 * q + e;
+            if (s >= NST) continue;
             const float b = hi ? f[2 * s + 1] : f[2 * s];
 #pragma unroll
             for (int mb = 0; mb < 5; ++mb)
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
     }
     Act x, y;
     zero(y);
-    mma_feat<EDGE_L1_CHUNKS>(lds + BUF_FLOATS, f, y.t, lane);
+    mma_feat<EDGE_L1_CHUNKS, (RD + 2) / 2>(lds + BUF_FLOATS, f, y.t, lane);     // RD inputs + bias: 9 (n_his 4) / 11 steps of 12
     __syncthreads();
     relu_one(y, lane);
     layer160<Q_FLOATS>(lds, g.w + WL::E_L2, g.w + WL::E_L3, y, x, tid, lane);
