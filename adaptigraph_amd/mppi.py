@@ -96,29 +96,38 @@ def optimize_action_mppi(act_seqs, reward_seqs, reward_weight=100.0, action_lowe
 @torch.no_grad()
 def mpc_iteration(state_cur, act_seq, model_rollout_fn, evaluate_traj_fn, action_lower_lim, action_upper_lim, n_sample,
                   device, noise_level=1.0, reward_weight=500.0, push_length=0.10, iter_index=0, rollout_best=True,
-                  act_seqs=None, group=None):
-    """Planner.trajectory_optimization_mppi with n_update_iter = 1 (planner.py:234-277, plan.py:199): sample ->
-    rollout -> evaluate -> MPPI update -> best candidate -> (optionally) roll the best out again.
+                  act_seqs=None, group=None, n_update_iter=1):
+    """Planner.trajectory_optimization_mppi (planner.py:234-277): per update iteration sample -> rollout -> evaluate ->
+    MPPI update; the best candidate over all iterations is kept and (optionally) rolled out once more.  plan.py:199 runs
+    it with n_update_iter = 1.
 
     model_rollout_fn(state_cur, act_seqs) and evaluate_traj_fn(state_seqs, act_seqs, state_cur=...) are the same
     partials plan.py builds (plan.py:175, 190).  `group`: shard the candidates over the ranks of that group; every
-    rank must call with the same generator state (or pass the same `act_seqs`)."""
+    rank must call with the same generator state (or pass the same `act_seqs`, which then serves the first iteration).
+    The whole candidate batch goes through one rollout call (the engine chunks on the device): the reference's
+    host-side loop over n_sample / n_sample_chunk chunks and its merge_res (plan.py:241-247) have nothing left to do."""
     from .sharding import shard_bounds, all_gather_costs
     import torch.distributed as dist
-    if act_seqs is None:
-        act_seqs = sample_action_seq(act_seq, action_lower_lim, action_upper_lim, n_sample, device,
-                                     iter_index=iter_index, noise_level=noise_level, push_length=push_length)
-    world = dist.get_world_size(None if group is True else group) if group is not None else 1
-    rank = dist.get_rank(None if group is True else group) if group is not None else 0
-    lo, hi = shard_bounds(act_seqs.shape[0], world, rank)
-    model_out = model_rollout_fn(state_cur, act_seqs[lo:hi])
-    eval_out = evaluate_traj_fn(model_out["state_seqs"], act_seqs[lo:hi], state_cur=state_cur)
-    reward_seqs = all_gather_costs(eval_out["reward_seqs"].contiguous(), act_seqs.shape[0],
-                                   None if group in (None, True) else group) if world > 1 else eval_out["reward_seqs"]
-    new_act_seq = optimize_action_mppi(act_seqs, reward_seqs, reward_weight, action_lower_lim, action_upper_lim, push_length)
-    best = torch.argmax(reward_seqs)
-    best_act_seq, best_reward = act_seqs[best], reward_seqs[best]
-    out = {"act_seq": best_act_seq, "mppi_act_seq": new_act_seq, "best_reward": best_reward, "reward_seqs": reward_seqs,
+    pg = None if group in (None, True) else group
+    world = dist.get_world_size(pg) if group is not None else 1
+    rank = dist.get_rank(pg) if group is not None else 0
+    best_act_seq = best_reward = reward_seqs = None
+    nominal = act_seq
+    for it in range(n_update_iter):
+        if act_seqs is None or it > 0:
+            act_seqs = sample_action_seq(nominal, action_lower_lim, action_upper_lim, n_sample, device,
+                                         iter_index=iter_index + it, noise_level=noise_level, push_length=push_length)
+        lo, hi = shard_bounds(act_seqs.shape[0], world, rank)
+        model_out = model_rollout_fn(state_cur, act_seqs[lo:hi])
+        eval_out = evaluate_traj_fn(model_out["state_seqs"], act_seqs[lo:hi], state_cur=state_cur)
+        reward_seqs = eval_out["reward_seqs"]
+        if world > 1:
+            reward_seqs = all_gather_costs(reward_seqs.contiguous(), act_seqs.shape[0], pg)
+        nominal = optimize_action_mppi(act_seqs, reward_seqs, reward_weight, action_lower_lim, action_upper_lim, push_length)
+        top = torch.argmax(reward_seqs)
+        if best_reward is None or bool(reward_seqs[top] > best_reward):       # planner.py:254-260
+            best_act_seq, best_reward = act_seqs[top], reward_seqs[top]
+    out = {"act_seq": best_act_seq, "mppi_act_seq": nominal, "best_reward": best_reward, "reward_seqs": reward_seqs,
            "best_model_output": None, "best_eval_output": None}
     if rollout_best:                                                                   # planner.py:268-271
         out["best_model_output"] = model_rollout_fn(state_cur, best_act_seq.unsqueeze(0))

@@ -371,6 +371,17 @@ def test_mpc_iteration_end_to_end(ag, O, dev):
     best = out["act_seq"].cpu().numpy()[None]
     want = O.dynamics(W, 3, cloud, best, task)["state_seqs"]
     assert np.abs(out["best_model_output"]["state_seqs"].cpu().numpy() - want).max() <= POS_TOL
+    # several update iterations (planner.py:240-260): iteration i perturbs the nominal sequence of iteration i-1, the best
+    # candidate over ALL iterations is returned - so its reward cannot be below the single-iteration result's
+    torch.manual_seed(5)
+    one = ag.mpc_iteration(s0, act_seq, rollout, evaluate, lo, hi, n_sample=48, device=dev, reward_weight=500.0,
+                           noise_level=0.3, rollout_best=False)
+    torch.manual_seed(5)                                                # same first-iteration samples
+    more = ag.mpc_iteration(s0, act_seq, rollout, evaluate, lo, hi, n_sample=48, device=dev, reward_weight=500.0,
+                            noise_level=0.3, n_update_iter=3)
+    assert float(more["best_reward"]) >= float(one["best_reward"])
+    again = evaluate(rollout(s0, more["act_seq"][None])["state_seqs"], more["act_seq"][None], state_cur=s0)["reward_seqs"]
+    assert more["best_model_output"]["state_seqs"].shape == (1, 2, 120, 3) and torch.isfinite(again).all()
 
 
 def test_single_graph_builder_vs_reference_golden(ag, dev):
