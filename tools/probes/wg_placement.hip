@@ -1,3 +1,4 @@
+// build: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 wg_placement.hip -o wg_placement   (then: gpurun -- tools/probes/wg_placement)
 // Probe: where do the workgroups of a chain-shaped launch (256 threads, 72 KB LDS -> two per CU) land, and can a
 // workgroup tell whether it is the first or the second on its CU?  Prints per block: XCC id, HW_ID fields, LDS_ALLOC.
 #include <hip/hip_runtime.h>
