@@ -330,7 +330,9 @@ int pick_slices(int B, int N) {
     // 384: 43.1, 512: 35.2, 1024: 41.9)
     static const int target = getenv("AG_EDGE_WGS") ? atoi(getenv("AG_EDGE_WGS")) : 256;
     int s = (target + B - 1) / B;
-    s = std::min(s, std::max(1, N / 64));
+    // a slice is at least 16 rows (one per wavefront of the workgroup): small batches are latency-bound, so a single
+    // graph is spread over as many workgroups as that allows (one rope graph: 4 -> 18 workgroups, 43 -> 13 us per launch)
+    s = std::min(s, std::max(1, N / 16));
     return std::max(1, std::min(s, 64));
 }
 
