@@ -55,71 +55,74 @@ struct ChamferDev {
     const float* x; const float* y; const uint8_t* xm; const uint8_t* ym; float* out;
     int R, N, M, By;
 };
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int CH_PT = 4;
+// Squared distance from CH_PT owned points (registers) to every point of the other cloud (SoA in LDS, length padded to
+// even with points parked at BIG).  The sweep is VALU-bound, so it runs on the packed fp32 pipe: two points of the other
+// cloud per step (v_pk_add/mul/fma_f32) and one v_min3_f32 folds both distances - 7 instructions per 2 evaluations.
+// A parked point gives dx*dx = +inf, which min() ignores; no select in the loop.
+__device__ __forceinline__ void chamfer_sweep(const float* os, int opad, const float (&qx)[CH_PT], const float (&qy)[CH_PT],
+                                              const float (&qz)[CH_PT], float (&m)[CH_PT]) {
+    const f2* ox = reinterpret_cast<const f2*>(os);
+    const f2* oy = reinterpret_cast<const f2*>(os + opad);
+    const f2* oz = reinterpret_cast<const f2*>(os + 2 * opad);
+    for (int i = 0; i < opad / 2; ++i) {
+        const f2 px = ox[i], py = oy[i], pz = oz[i];
+#pragma unroll
+        for (int k = 0; k < CH_PT; ++k) {
+            const f2 dx = px - qx[k], dy = py - qy[k], dz = pz - qz[k];
+            const f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+            m[k] = fminf(fminf(m[k], d.x), d.y);
+        }
+    }
+}
 __global__ __launch_bounds__(CT) void k_chamfer(ChamferDev a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[CT];
     const int r = blockIdx.x, tid = threadIdx.x;
-    float* xs = sm;                 // [3][N]
-    float* ys = sm + 3 * a.N;       // [3][M]
+    const int Np = (a.N + 1) & ~1, Mp = (a.M + 1) & ~1;
+    float* xs = sm;                 // [3][Np]
+    float* ys = sm + 3 * Np;        // [3][Mp]
     const float* xr = a.x + (long)r * a.N * 3;
     const float* yr = a.y + (long)(a.By == 1 ? 0 : r) * a.M * 3;
     const uint8_t* xm = a.xm ? a.xm + (long)r * a.N : nullptr;
     const uint8_t* ym = a.ym ? a.ym + (long)(a.By == 1 ? 0 : r) * a.M : nullptr;
     const float BIG = 3.0e38f;
-    for (int i = tid; i < a.N; i += CT) {
-        const bool v = xm ? xm[i] != 0 : true;             // masked-out points are parked at "infinity"
-        xs[i] = v ? xr[3 * i] : BIG; xs[a.N + i] = v ? xr[3 * i + 1] : BIG; xs[2 * a.N + i] = v ? xr[3 * i + 2] : BIG;
+    for (int i = tid; i < Np; i += CT) {
+        const bool v = i < a.N && (xm ? xm[i] != 0 : true);   // masked-out points (and the pad) are parked at "infinity"
+        xs[i] = v ? xr[3 * i] : BIG; xs[Np + i] = v ? xr[3 * i + 1] : BIG; xs[2 * Np + i] = v ? xr[3 * i + 2] : BIG;
     }
-    for (int j = tid; j < a.M; j += CT) {
-        const bool v = ym ? ym[j] != 0 : true;
-        ys[j] = v ? yr[3 * j] : BIG; ys[a.M + j] = v ? yr[3 * j + 1] : BIG; ys[2 * a.M + j] = v ? yr[3 * j + 2] : BIG;
+    for (int j = tid; j < Mp; j += CT) {
+        const bool v = j < a.M && (ym ? ym[j] != 0 : true);
+        ys[j] = v ? yr[3 * j] : BIG; ys[Mp + j] = v ? yr[3 * j + 1] : BIG; ys[2 * Mp + j] = v ? yr[3 * j + 2] : BIG;
     }
     __syncthreads();
     float sum_y = 0.f, cnt_y = 0.f, sum_x = 0.f, cnt_x = 0.f;
-    // register tiling: a lane owns PT points of one cloud, so every LDS broadcast of a point of the other cloud feeds
-    // PT distance evaluations (the sweep is LDS-issue bound otherwise)
-    constexpr int PT = 4;
-    for (int j0 = tid * PT; j0 < a.M; j0 += CT * PT) {     // for every y point the nearest x
-        float yx[PT], yy[PT], yz[PT], m[PT];
+    // register tiling: a lane owns CH_PT points of one cloud, so every LDS read of two points of the other cloud feeds
+    // 2*CH_PT distance evaluations
+    for (int j0 = tid * CH_PT; j0 < a.M; j0 += CT * CH_PT) {     // for every y point the nearest x
+        float qx[CH_PT], qy[CH_PT], qz[CH_PT], m[CH_PT];
 #pragma unroll
-        for (int k = 0; k < PT; ++k) {
+        for (int k = 0; k < CH_PT; ++k) {
             const int j = min(j0 + k, a.M - 1);
-            yx[k] = ys[j]; yy[k] = ys[a.M + j]; yz[k] = ys[2 * a.M + j]; m[k] = BIG;
+            qx[k] = ys[j]; qy[k] = ys[Mp + j]; qz[k] = ys[2 * Mp + j]; m[k] = BIG;
         }
-        for (int i = 0; i < a.N; ++i) {
-            const float px = xs[i], py = xs[a.N + i], pz = xs[2 * a.N + i];
-            const bool dead = px >= BIG;
+        chamfer_sweep(xs, Np, qx, qy, qz, m);
 #pragma unroll
-            for (int k = 0; k < PT; ++k) {
-                const float dx = px - yx[k], dy = py - yy[k], dz = pz - yz[k];
-                const float d = dead ? BIG : (dx * dx + dy * dy) + dz * dz;
-                m[k] = fminf(m[k], d);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < PT; ++k)
-            if (j0 + k < a.M && yx[k] < BIG) { sum_y += sqrtf(m[k]); cnt_y += 1.f; }
+        for (int k = 0; k < CH_PT; ++k)
+            if (j0 + k < a.M && qx[k] < BIG) { sum_y += sqrtf(m[k]); cnt_y += 1.f; }
     }
-    for (int i0 = tid * PT; i0 < a.N; i0 += CT * PT) {     // for every x point the nearest y
-        float xx[PT], xy[PT], xz[PT], m[PT];
+    for (int i0 = tid * CH_PT; i0 < a.N; i0 += CT * CH_PT) {     // for every x point the nearest y
+        float qx[CH_PT], qy[CH_PT], qz[CH_PT], m[CH_PT];
 #pragma unroll
-        for (int k = 0; k < PT; ++k) {
+        for (int k = 0; k < CH_PT; ++k) {
             const int i = min(i0 + k, a.N - 1);
-            xx[k] = xs[i]; xy[k] = xs[a.N + i]; xz[k] = xs[2 * a.N + i]; m[k] = BIG;
+            qx[k] = xs[i]; qy[k] = xs[Np + i]; qz[k] = xs[2 * Np + i]; m[k] = BIG;
         }
-        for (int j = 0; j < a.M; ++j) {
-            const float px = ys[j], py = ys[a.M + j], pz = ys[2 * a.M + j];
-            const bool dead = px >= BIG;
+        chamfer_sweep(ys, Mp, qx, qy, qz, m);
 #pragma unroll
-            for (int k = 0; k < PT; ++k) {
-                const float dx = xx[k] - px, dy = xy[k] - py, dz = xz[k] - pz;
-                const float d = dead ? BIG : (dx * dx + dy * dy) + dz * dz;
-                m[k] = fminf(m[k], d);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < PT; ++k)
-            if (i0 + k < a.N && xx[k] < BIG) { sum_x += sqrtf(m[k]); cnt_x += 1.f; }
+        for (int k = 0; k < CH_PT; ++k)
+            if (i0 + k < a.N && qx[k] < BIG) { sum_x += sqrtf(m[k]); cnt_x += 1.f; }
     }
     const float sy = block_sum(sum_y, red), cy = block_sum(cnt_y, red);
     const float sx = block_sum(sum_x, red), cx = block_sum(cnt_x, red);
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(CT) void k_penalty(PenDev a) {
 hipError_t launch_chamfer(const float* x, const float* y, const uint8_t* xm, const uint8_t* ym, int R, int N, int M,
                           int By, float* out, hipStream_t st) {
     ChamferDev a{x, y, xm, ym, out, R, N, M, By};
-    const size_t lds = (size_t)(3 * N + 3 * M) * 4;
+    const size_t lds = (size_t)(3 * ((N + 1) & ~1) + 3 * ((M + 1) & ~1)) * 4;
     static unsigned long long attr_devices = 0;              // per-device function attribute (see ag_edges.hip)
     int dev_id = 0;
     if (hipGetDevice(&dev_id) != hipSuccess) dev_id = 0;
@@ -224,6 +227,6 @@ hipError_t launch_penalty(const float* state_pred, const float* action, const fl
     hipLaunchKernelGGL(k_penalty, dim3(B * H), dim3(CT), 0, st, a);
     return hipGetLastError();
 }
-size_t chamfer_max_points() { return (160 * 1024 - 2048) / 12; }
+size_t chamfer_max_points() { return (160 * 1024 - 2048) / 12 - 2; }   // both clouds, each padded to even length
 
 }  // namespace ag
