@@ -31,6 +31,7 @@
 //   k_edge_count : per-row kept list (ELL) + degree, slice totals, connect_tools_all flag
 //   k_edge_emit  : scan of degrees -> row_ptr, then writes (recv, send) in order
 #include "ag_common.h"
+#include <cstdlib>
 
 namespace ag {
 
@@ -51,6 +52,7 @@ struct EdgeDev {
     int* ns_edge; int* n_ns;
     int* deg; int* slice_tot; int* cta_flag;
     int* recv; int* send; int* row_ptr; int* n_edges; int* overflow; int max_nR; int zero_on_overflow;
+    int block_min_rows;                  // slices with at least this many rows take the 64-rows-per-wavefront path
 };
 
 __device__ __forceinline__ float dist_exact(float xi, float yi, float zi, float xj, float yj, float zj) {
@@ -76,18 +78,18 @@ struct EdgeLds {
     uint8_t* fl;                // [Np] bit0 valid, bit1 tool
 };
 __host__ __device__ inline size_t edge_lds_bytes(int N) {
-    const size_t Np = (size_t)((N + 3) & ~3);
-    return (size_t)EWAVES * CAP * 8 + EW * 4 + (2 * Np + 8) * 2 + Np * 12 + 6 * MAXCH * 4 + 64 * 4 + Np + 16;
+    const size_t Np = (size_t)((N + 3) & ~3), Nc = (size_t)((N + 63) & ~63);   // Nc: positions, whole sender chunks
+    return (size_t)EWAVES * CAP * 8 + EW * 4 + (2 * Np + 8) * 2 + Nc * 12 + 6 * MAXCH * 4 + 64 * 4 + Np + 16;
 }
 __device__ __forceinline__ EdgeLds carve(unsigned char* base, int N) {
     EdgeLds l;
-    const int Np = (N + 3) & ~3;
+    const int Np = (N + 3) & ~3, Nc = (N + 63) & ~63;
     l.keys = reinterpret_cast<unsigned long long*>(base);
     l.scan = reinterpret_cast<int*>(base + (size_t)EWAVES * CAP * 8);
     l.x = reinterpret_cast<float*>(l.scan + EW);
-    l.y = l.x + Np;
-    l.z = l.y + Np;
-    l.bb = l.z + Np;
+    l.y = l.x + Nc;
+    l.z = l.y + Nc;
+    l.bb = l.z + Nc;
     l.misc = reinterpret_cast<int*>(l.bb + 6 * MAXCH);
     l.tprefix = reinterpret_cast<unsigned short*>(l.misc + 64);
     l.tlist = l.tprefix + Np + 4;
@@ -141,6 +143,14 @@ __device__ void load_candidate(const EdgeDev& a, const EdgeLds& l, int b, bool w
         }
     }
     if (lane == 0 && ntool) atomicAdd(&l.misc[2], ntool);
+    if (want_pos) {
+        // invalid senders and the pad up to a whole chunk are parked at x = +inf: their distance to any receiver is
+        // +inf (or NaN), which fails the adjacency test like the reference's 1e10 (graph.py:253-256) - the block sweep
+        // (block_topk) then needs no validity flag per pair.  Disjoint from what the box pass above reads (valid j only).
+        const int Nc = (a.N + 63) & ~63;
+        for (int j = threadIdx.x; j < Nc; j += EW)
+            if (j >= a.N || !(l.fl[j] & 1)) { l.x[j] = __builtin_huge_valf(); l.y[j] = 0.f; l.z[j] = 0.f; }
+    }
     __syncthreads();
 }
 
@@ -314,6 +324,128 @@ __device__ __forceinline__ bool member_radius(const EdgeDev& a, const EdgeLds& l
     return within && !(fi & 2);                            // graph.py:283,285 | :120
 }
 
+// ---- 64 receiver rows per wavefront (one per lane), top-k active.  The per-row path above spends ~400 wave
+// instructions of control per row for ~250 useful pair tests; here the control is per BLOCK of 64 consecutive rows:
+//   * chunk culling with the bounding box of the block's receivers: fl(x_i - max_x) >= fl(rmin_x - max_x) >= thr for
+//     every receiver of the block (rounding is monotonic), so a chunk culled for the box is culled for each receiver
+//     by the exact per-receiver argument in the header; surviving chunks are a superset, every pair in them is tested
+//     exactly, so the result cannot change;
+//   * sweep: the senders of a surviving chunk are LDS broadcasts (four per ds_read_b128), every lane tests them against
+//     ITS receiver with the same spelled-out arithmetic and shifts the outcome into a 2 x 32-bit hit mask;
+//   * each lane then walks its own hits (recomputing the distance - same operations, same bits) and keeps the KMAX
+//     smallest (distance, sender) keys sorted in registers: the same set the rank-counting selection keeps;
+//   * the kept senders leave in ascending index order, as the per-row path writes them.
+// Tool receivers (tool-tool masking, graph.py:257-260, and the connect_tools_all census) stay on the per-row path.
+template <int KMAX>
+__device__ __forceinline__ void topk_insert(unsigned long long (&best)[KMAX], unsigned long long x) {
+    bool c[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) c[s] = x < best[s];
+#pragma unroll
+    for (int s = KMAX - 1; s > 0; --s) best[s] = c[s - 1] ? best[s - 1] : (c[s] ? x : best[s]);
+    best[0] = c[0] ? x : best[0];
+}
+__device__ __forceinline__ unsigned long long survivors_box(const EdgeLds& l, int N, float lox, float hix, float loy,
+                                                            float hiy, float loz, float hiz, float thr) {
+    thr = fabsf(thr);
+    const int lane = lane_id();
+    const int nch = (N + 63) >> 6;
+    bool keep = false;
+    if (lane < nch) {
+        const float mnx = l.bb[0 * MAXCH + lane], mxx = l.bb[1 * MAXCH + lane];
+        const float mny = l.bb[2 * MAXCH + lane], mxy = l.bb[3 * MAXCH + lane];
+        const float mnz = l.bb[4 * MAXCH + lane], mxz = l.bb[5 * MAXCH + lane];
+        const bool out = (__fsub_rn(lox, mxx) >= thr) || (__fsub_rn(mnx, hix) >= thr) ||
+                         (__fsub_rn(loy, mxy) >= thr) || (__fsub_rn(mny, hiy) >= thr) ||
+                         (__fsub_rn(loz, mxz) >= thr) || (__fsub_rn(mnz, hiz) >= thr);
+        keep = !out;
+    }
+    return __ballot(keep);
+}
+typedef float ef4 __attribute__((ext_vector_type(4)));
+typedef float ef2 __attribute__((ext_vector_type(2)));
+// 32 consecutive senders starting at LDS index j0 (a multiple of 4) against this lane's receiver; sender s -> bit 31-s.
+// Two senders per instruction on the packed fp32 pipe: v_pk_add/v_pk_mul are the same IEEE operations per element as
+// the scalar ones of dist_exact (no FMA: the file is built with -ffp-contract=off), so the distances are the same bits.
+__device__ __forceinline__ unsigned sweep32(const EdgeLds& l, int j0, float xi, float yi, float zi, float thr2) {
+    unsigned m = 0;
+    const ef2 rx = {xi, xi}, ry = {yi, yi}, rz = {zi, zi};
+#pragma unroll 2
+    for (int q = 0; q < 8; ++q) {
+        const ef4 X = *reinterpret_cast<const ef4*>(l.x + j0 + 4 * q);    // same address in every lane: broadcast
+        const ef4 Y = *reinterpret_cast<const ef4*>(l.y + j0 + 4 * q);
+        const ef4 Z = *reinterpret_cast<const ef4*>(l.z + j0 + 4 * q);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const ef2 sx = h ? X.zw : X.xy, sy = h ? Y.zw : Y.xy, sz = h ? Z.zw : Z.xy;
+            const ef2 dx = rx - sx, dy = ry - sy, dz = rz - sz;
+            const ef2 d = ((dx * dx) + (dy * dy)) + (dz * dz);            // graph.py:251-252, element by element
+            m = m + m + ((__fsub_rn(d.x, thr2) < 0.0f) ? 1u : 0u);        // graph.py:267
+            m = m + m + ((__fsub_rn(d.y, thr2) < 0.0f) ? 1u : 0u);
+        }
+    }
+    return m;
+}
+template <int KMAX>
+__device__ void block_topk(const EdgeDev& a, const EdgeLds& l, int b, int rbase, int r1, float thr, float thr2) {
+    const int lane = lane_id();
+    const int i = rbase + lane;
+    const bool inr = i < r1;
+    const int ii = inr ? i : rbase;
+    const int fi = l.fl[ii];
+    const bool act = inr && (fi & 1) && !(fi & 2);
+    const float xi = l.x[ii], yi = l.y[ii], zi = l.z[ii];
+    unsigned long long best[KMAX];
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) best[t] = KEY_INF;
+    if (__ballot(act)) {
+        const float INF = __builtin_huge_valf();
+        const float lox = wave_min(act ? xi : INF), hix = wave_max(act ? xi : -INF);
+        const float loy = wave_min(act ? yi : INF), hiy = wave_max(act ? yi : -INF);
+        const float loz = wave_min(act ? zi : INF), hiz = wave_max(act ? zi : -INF);
+        unsigned long long todo = survivors_box(l, a.N, lox, hix, loy, hiy, loz, hiz, thr);
+        while (todo) {
+            const int c = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            unsigned m0 = sweep32(l, 64 * c, xi, yi, zi, thr2);
+            unsigned m1 = sweep32(l, 64 * c + 32, xi, yi, zi, thr2);
+            if (!act) { m0 = 0; m1 = 0; }
+            while (__ballot((m0 | m1) != 0)) {              // every lane walks its own hits of this chunk
+                const bool has = (m0 | m1) != 0;
+                const bool lo = m0 != 0;
+                const unsigned w = lo ? m0 : m1;
+                const int bit = has ? __builtin_ctz(w) : 0;
+                const int sdr = has ? 64 * c + (lo ? 31 : 63) - bit : 64 * c;
+                if (lo) m0 &= m0 - 1; else m1 &= m1 - 1;
+                const float d = dist_exact(xi, yi, zi, l.x[sdr], l.y[sdr], l.z[sdr]);
+                const unsigned long long key = has ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)sdr) : KEY_INF;
+                topk_insert<KMAX>(best, key);
+            }
+        }
+    }
+    if (!inr || (fi & 2)) return;                           // tool rows: per-row path writes their degree
+    int n = 0;
+    if (act) {
+        int js[KMAX]; bool outm[KMAX];
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            const bool kept = t < a.k && best[t] != KEY_INF;
+            js[t] = kept ? (int)(best[t] & 0xffffffffull) : 0;
+            outm[t] = kept && (!a.cta || !(l.fl[js[t]] & 2));  // graph.py:283-286: tool senders are decided at emit
+        }
+        int* ell_row = a.ell + (long)b * a.ell_bstride + (long)i * a.ell_stride;
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            int pos = 0;
+#pragma unroll
+            for (int u = 0; u < KMAX; ++u) pos += (outm[u] && js[u] < js[t]) ? 1 : 0;
+            if (outm[t]) { ell_row[pos] = js[t]; ++n; }
+        }
+    }
+    a.deg[(long)b * a.N + i] = n;
+}
+constexpr int BLOCK_MIN_ROWS = 256;   // below: the per-row path (16 wavefronts on 16 rows) has the shorter critical path
+
 __device__ __forceinline__ float thr_of(const EdgeDev& a, int b) { return a.thr_vec ? a.thr_vec[b] : a.thr; }
 // squared threshold of the adjacency test: fp32*fp32 for the batch builder (graph.py:250), a caller-supplied value
 // for the single-graph builder, whose Python squares in double before the fp32 subtraction (graph.py:86,101)
@@ -352,10 +484,19 @@ __global__ __launch_bounds__(EW) void k_edge_count(EdgeDev a) {
     const int r1 = min(a.N, r0 + a.rows_per_slice);
     const int ntool = l.misc[2];
     // pass 1: rows of this slice (+ every tool row, whose non-tool senders decide the batch flag graph.py:277)
+    const bool blocks = a.topk_active && a.k <= 20 && r1 - r0 >= a.block_min_rows;
+    if (blocks) {                                          // non-tool rows, 64 per wavefront
+        for (int rb = r0 + 64 * wave; rb < r1; rb += 64 * EWAVES) {
+            if (a.k <= 5) block_topk<5>(a, l, b, rb, r1, thr, thr2);
+            else if (a.k <= 10) block_topk<10>(a, l, b, rb, r1, thr, thr2);
+            else block_topk<20>(a, l, b, rb, r1, thr, thr2);
+        }
+    }
     for (int i = wave; i < a.N; i += EWAVES) {
         const bool mine = i >= r0 && i < r1;
         const bool is_tool = l.fl[i] & 2;
         if (!mine && !(a.cta == 1 && is_tool)) continue;   // wave-uniform
+        if (blocks && !is_tool) continue;                  // done above
         int raw = 0, n;
         if (a.topk_active) n = row_topk(a, l, i, thr, thr2, a.ell + (long)b * a.ell_bstride + (long)i * a.ell_stride, &raw);
         else n = row_radius_count(a, l, i, thr, thr2, 0, &raw);
@@ -580,6 +721,8 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     a.ns_edge = h.ns_edge; a.n_ns = h.n_ns;
     a.recv = h.recv; a.send = h.send; a.row_ptr = h.row_ptr; a.n_edges = h.n_edges; a.overflow = h.overflow;
     a.max_nR = h.max_nR; a.zero_on_overflow = h.zero_on_overflow;
+    a.block_min_rows = BLOCK_MIN_ROWS;
+    if (const char* e = getenv("AG_EDGE_BLOCK_MIN")) a.block_min_rows = atoi(e);   // A/B switch; results identical
     const size_t lds = edge_lds_bytes(h.N);
     // the > 64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: track it per device ordinal
     static unsigned long long attr_devices = 0;

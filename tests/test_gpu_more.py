@@ -668,3 +668,51 @@ def test_latency_kernels_equal_throughput_kernels_bitwise(ag, O, dev, material, 
     assert torch.equal(auto, out["0"])
     want = O.dynamics(W, 3, cloud, a.cpu().numpy(), task)["state_seqs"]
     assert np.abs(auto.cpu().numpy() - want).max() <= POS_TOL
+
+
+@pytest.mark.parametrize("N_o,M,topk,thr,pitch,cta", [
+    (2025, 1, 5, 0.75, 0.3, True),        # the benchmarked cloth shape: two 1013-row slices per candidate
+    (1024, 5, 20, 0.40, 0.12, True),      # granular: k = 20 kept in registers per lane
+    (300, 1, 10, 0.5, 0.05, False),       # rope-sized: five blocks, most lanes of the last one idle
+    (640, 2, 3, 0.3, 0.1, True),          # k below the smallest register tile (5)
+])
+def test_edge_block_schedule_equals_row_schedule_bitwise(ag, dev, N_o, M, topk, thr, pitch, cta):
+    """Large batches build the top-k graph 64 receiver rows per wavefront (one row per lane, hit masks + per-lane sorted
+    top-k: csrc/ag_edges.hip block_topk); AG_EDGE_BLOCK_MIN switches back to one row per wavefront.  Same edge lists,
+    same CSR, same degrees - with holes in the masks, an empty candidate tail, far-away tools and exact distance ties."""
+    import os
+    rng = np.random.default_rng(N_o + topk)
+    B, N = 130, N_o + M
+    side = int(np.ceil(np.sqrt(N_o)))
+    g = np.arange(side) * pitch
+    xx, zz = np.meshgrid(g, g, indexing="ij")
+    base = np.stack([xx.ravel(), np.zeros(side * side), zz.ravel()], 1)[:N_o].astype(np.float32)
+    states = np.zeros((B, N, 3), np.float32)
+    mask = np.ones((B, N), bool)
+    tool = np.zeros((B, N), bool)
+    tool[:, N_o:] = True
+    for b in range(B):
+        jitter = 0.0 if b % 9 == 0 else pitch / 6               # every ninth candidate is an exact lattice: mass ties
+        states[b, :N_o] = base + rng.normal(0, 1, base.shape).astype(np.float32) * np.float32(jitter)
+        states[b, N_o:] = states[b, rng.integers(0, N_o, M)] + rng.normal(0, pitch / 3, (M, 3))
+        if b % 4 == 1:
+            mask[b, :N_o] = rng.uniform(size=N_o) < 0.7          # holes
+        if b % 4 == 2:
+            mask[b, N_o // 3:N_o] = False                        # ragged tail
+        if b % 5 == 3:
+            states[b, N_o:, 0] += 1e3                            # tool out of reach: connect_tools_all flag stays off
+    args = (torch.from_numpy(states).to(dev), thr, torch.from_numpy(mask).to(dev), torch.from_numpy(tool).to(dev), topk, cta)
+    out = {}
+    for mode, val in (("blocks", "1"), ("rows", "1000000000")):
+        os.environ["AG_EDGE_BLOCK_MIN"] = val
+        try:
+            el = ag.construct_edges_index(*args)
+            out[mode] = [t.cpu().numpy().copy() for t in (el.n_edges, el.recv, el.send, el.row_ptr)]
+        finally:
+            os.environ.pop("AG_EDGE_BLOCK_MIN", None)
+    n = out["rows"][0]
+    assert n.min() > 0 and np.array_equal(out["blocks"][0], n)
+    assert np.array_equal(out["blocks"][3], out["rows"][3])
+    for b in range(B):
+        assert np.array_equal(out["blocks"][1][b, :n[b]], out["rows"][1][b, :n[b]]), b
+        assert np.array_equal(out["blocks"][2][b, :n[b]], out["rows"][2][b, :n[b]]), b

@@ -60,7 +60,16 @@ def _edges_to_lists(el):
 
 
 # ------------------------------------------------------------------------------------------------- edges
-def test_edges_vs_reference_golden(ag, dev):
+@pytest.fixture(params=["auto", "rows", "blocks"])
+def edge_path(request, monkeypatch):
+    """The top-k builder has two row schedules with identical results: one receiver row per wavefront, and 64 rows per
+    wavefront (taken for slices of >= 256 rows).  AG_EDGE_BLOCK_MIN forces either one at any slice size."""
+    if request.param != "auto":
+        monkeypatch.setenv("AG_EDGE_BLOCK_MIN", "1" if request.param == "blocks" else "1000000000")
+    return request.param
+
+
+def test_edges_vs_reference_golden(ag, dev, edge_path):
     g = load_golden("edges_batch")
     cases = json.loads(bytes(g["cases_json"]).decode())
     for ci, c in enumerate(cases):
@@ -108,7 +117,7 @@ def test_dense_dropin_matches_reference_layout(ag, dev):
     (1, 1, 10, 0.5, True, 6),         # degenerate: single object particle
     (4094, 2, 10, 0.12, True, 7),     # the builder's maximum: 4096 particles (64 sender chunks)
 ])
-def test_edges_vs_oracle(ag, dev, N_o, M, topk, thr, cta, seed):
+def test_edges_vs_oracle(ag, dev, edge_path, N_o, M, topk, thr, cta, seed):
     from oracle import adaptigraph_oracle as O
     rng = np.random.default_rng(seed)
     B, N = 3, N_o + M
@@ -136,7 +145,7 @@ def test_edges_vs_oracle(ag, dev, N_o, M, topk, thr, cta, seed):
         assert np.array_equal(r, wr) and np.array_equal(s, ws), b
 
 
-def test_edges_exact_ties_use_distance_then_index(ag, dev):
+def test_edges_exact_ties_use_distance_then_index(ag, dev, edge_path):
     """Regular lattice: mass ties at the k-th boundary.  The build's documented rule is (distance, index)."""
     from oracle import adaptigraph_oracle as O
     g = (np.arange(12) * 0.25).astype(np.float32)
