@@ -6,8 +6,10 @@ the random numbers - with the same torch calls, shapes and order as the referenc
 the reference's draws - and hands device pointers to the C-ABI.  There is no CPU path.
 
 What the engine changes upstream: the reference evaluates n_sample = 20000 in 40 host-side chunks of 500
-(plan.py:177-182, 241-247) because its dense rollout does not fit; here one call takes the whole batch (the engine
-chunks on the device), optionally sharded over the ranks of a torch.distributed group.
+(plan.py:177-182, 241-247) because its dense rollout does not fit.  `mpc_iteration` here takes the whole batch in one call
+(the engine chunks on the device), optionally sharded over the ranks of a torch.distributed group - with the cost
+normalisation over the whole batch.  The reference's chunk-local semantics are kept by planner.Planner
+(trajectory_optimization_chunked), which is what a drop-in for plan.py uses.
 """
 from __future__ import annotations
 

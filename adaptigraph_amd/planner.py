@@ -1,0 +1,257 @@
+"""`Planner` behind the reference's class interface (src/planning/real_world/planner.py:38-323), MPPI only.
+
+Same config dictionary, same methods, same result dictionaries: plan.py:177-247 and random_interact.py:168-214 can
+construct it and call `trajectory_optimization` / `merge_res` unchanged.  The class is host logic around the two
+callables of the config (`model_rollout_fn` = forward_dynamics.dynamics, `evaluate_traj_fn` = running_cost): it owns no
+arithmetic of the hot path.  What is new:
+
+* `trajectory_optimization_chunked(state_cur, act_seq, n_chunk)` = the caller's loop
+      for ci in range(n_chunk): res_all.append(planner.trajectory_optimization(state_cur, act_seq))
+      res = planner.merge_res(res_all)                                               (plan.py:241-247)
+  with ONE rollout call for the candidates of all chunks and ONE for the chunk winners.  The reference needs the
+  chunks because its dense rollout does not fit 20,000 candidates; the engine does not, but the chunks are part of
+  the semantics - `running_cost` normalises by maxima over the chunk it is given (plan.py:37, losses.py:62) and the
+  winners are compared by a batch-of-one re-evaluation - so the chunked entry evaluates chunk by chunk and merges
+  exactly like the loop.  Per-candidate rollouts do not depend on what else is in the batch, hence the
+  result equals the loop's bit for bit (tests/test_gpu_more.py).
+* `group` (config key, optional): the chunks are dealt to the ranks of a torch.distributed group; every rank draws all
+  samples (same seed), rolls out and evaluates its chunks, the chunk winners (n_chunk x n_look_ahead x action_dim
+  floats) are all-gathered, and every rank re-evaluates the winners itself - no batch-global reduction crosses ranks.
+* `planner_type` 'GD' raises NotImplementedError: it differentiates through the rollout and the engine has no backward.
+
+The progress lines the reference prints on every call go to stdout only with `verbose`.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def farthest_points(points, num, init_idx=-1):
+    """Greedy farthest-point subset of `points` (n, c) -> (num, c), the rule of planner.py:15-36: start from the row
+    whose second half differs most from its first half (or `init_idx`), then always take the row farthest from the
+    chosen set; ties go to the lowest index (numpy argmax)."""
+    pts = np.asarray(points)
+    n, c = pts.shape
+    assert n > 0
+    if init_idx == -1:
+        half = c // 2
+        first = int(np.argmax(np.linalg.norm(pts[:, half:] - pts[:, :half], axis=1)))
+    else:
+        first = int(init_idx)
+    chosen = [first]
+    nearest = np.linalg.norm(pts - pts[first], axis=1)
+    while len(chosen) < num:
+        nxt = int(np.argmax(nearest))
+        chosen.append(nxt)
+        nearest = np.minimum(nearest, np.linalg.norm(pts - pts[nxt], axis=1))
+    return pts[chosen]
+
+
+class Planner(object):
+    _REQUIRED = ("action_dim", "model_rollout_fn", "evaluate_traj_fn", "n_sample", "n_look_ahead", "n_update_iter",
+                 "reward_weight", "action_lower_lim", "action_upper_lim", "planner_type")
+
+    def __init__(self, config):
+        """config keys: planner.py:40-76 (required) and :89-112 (optional), plus the optional `group`."""
+        for k in self._REQUIRED:
+            if k not in config:
+                raise KeyError(k)
+        self.config = config
+        self.action_dim = config["action_dim"]
+        self.model_rollout = config["model_rollout_fn"]
+        self.evaluate_traj = config["evaluate_traj_fn"]
+        self.n_sample = config["n_sample"]
+        self.n_look_ahead = config["n_look_ahead"]
+        self.n_update_iter = config["n_update_iter"]
+        self.reward_weight = config["reward_weight"]
+        self.action_lower_lim = config["action_lower_lim"]
+        self.action_upper_lim = config["action_upper_lim"]
+        self.planner_type = config["planner_type"]
+        assert self.planner_type in ["GD", "MPPI", "MPPI_GD"]
+        assert type(self.action_lower_lim) == torch.Tensor and type(self.action_upper_lim) == torch.Tensor
+        assert self.action_lower_lim.shape == (self.action_dim,)
+        assert self.action_upper_lim.shape == (self.action_dim,)
+        self.device = config.get("device", "cuda")
+        self.verbose = config.get("verbose", False)
+        self.sample_action_sequences = config.get("sampling_action_seq_fn", self.sample_action_sequences_default)
+        self.clip_action_sequences = config.get("clip_action_seq_fn", self.clip_actions_default)
+        self.optimize_action_mppi = config.get("optimize_action_mppi_fn", self.optimize_action_mppi_default)
+        self.noise_type = config.get("noise_type", "normal")
+        assert self.noise_type in ["normal", "fps"]
+        self.noise_level = config.get("noise_level", 0.1)
+        self.n_his = config.get("n_his", 1)
+        self.rollout_best = config.get("rollout_best", True)
+        self.lr = config.get("lr", 1e-3)
+        self.group = config.get("group", None)
+        self.chunk_id = 0
+        self.total_chunks = 1
+
+    # ------------------------------------------------------------------------------------------ defaults of the config
+    def sample_action_sequences_default(self, act_seq, iter_index=None):
+        """planner.py:118-166 -> (n_sample, n_look_ahead, action_dim).  'normal': low-pass filtered Gaussian
+        perturbations of the nominal sequence (filter 0.7, one torch.normal draw per look-ahead step), clamped to the
+        limits; 'fps': farthest-point subset of a 0.02 grid over the action box, repeated along the horizon.
+        (`iter_index` is accepted because the MPPI loop passes it to whatever sampler is configured.)"""
+        assert type(act_seq) == torch.Tensor and act_seq.shape == (self.n_look_ahead, self.action_dim)
+        if self.noise_type == "fps":
+            lo, hi = self.action_lower_lim.cpu().numpy(), self.action_upper_lim.cpu().numpy()
+            axes = [np.arange(lo[d], hi[d], 0.02) for d in range(self.action_dim)]
+            grid = np.stack(np.meshgrid(*axes), axis=-1).reshape(-1, self.action_dim)
+            picked = torch.from_numpy(farthest_points(grid, self.n_sample)).to(self.device).float()
+            return picked.unsqueeze(1).repeat(1, self.n_look_ahead, 1)
+        if self.noise_type != "normal":
+            raise ValueError("unknown noise type: %s" % self.noise_type)
+        keep = 0.7
+        out = act_seq.clone().unsqueeze(0).repeat(self.n_sample, 1, 1)
+        drift = torch.zeros((self.n_sample, self.action_dim), dtype=out.dtype, device=self.device)
+        for t in range(self.n_look_ahead):
+            noise = torch.normal(0, self.noise_level, (self.n_sample, self.action_dim), device=self.device)
+            drift = keep * noise + drift * (1. - keep)
+            out[:, t] += drift
+            out[:, t] = torch.clamp(out[:, t], self.action_lower_lim, self.action_upper_lim)
+        return out
+
+    def clip_actions_default(self, act_seqs):
+        """planner.py:226-230: clamp in place, return the same tensor."""
+        act_seqs.data.clamp_(self.action_lower_lim, self.action_upper_lim)
+        return act_seqs
+
+    def optimize_action_mppi_default(self, act_seqs, reward_seqs):
+        """planner.py:204-206: softmax(reward * reward_weight)-weighted mean of the sampled sequences, clipped."""
+        w = torch.softmax(reward_seqs * self.reward_weight, dim=0)
+        return self.clip_action_sequences(torch.sum(act_seqs * w[:, None, None], dim=0))
+
+    def optimize_action(self, act_seqs, reward_seqs, optimizer=None):
+        assert type(act_seqs) == torch.Tensor and type(reward_seqs) == torch.Tensor
+        assert act_seqs.shape == (self.n_sample, self.n_look_ahead, self.action_dim)
+        assert reward_seqs.shape == (self.n_sample,)
+        if self.planner_type == "MPPI":
+            return self.optimize_action_mppi(act_seqs, reward_seqs)
+        if self.planner_type == "GD":
+            raise NotImplementedError("planner_type 'GD' differentiates through the rollout; the HIP engine is inference-only")
+        if self.planner_type == "MPPI_GD":
+            raise NotImplementedError
+        raise ValueError("unknown planner type: %s" % self.planner_type)
+
+    # ------------------------------------------------------------------------------------------------- optimisation
+    def trajectory_optimization(self, state_cur, act_seq):
+        """planner.py:185-202.  -> {'act_seq', 'model_outputs', 'eval_outputs', 'best_model_output', 'best_eval_output'}"""
+        assert type(state_cur) == torch.Tensor and type(act_seq) == torch.Tensor
+        assert act_seq.shape == (self.n_look_ahead, self.action_dim)
+        if self.planner_type == "MPPI":
+            return self.trajectory_optimization_mppi(state_cur, act_seq)
+        if self.planner_type == "GD":
+            return self.trajectory_optimization_gd(state_cur, act_seq)
+        if self.planner_type == "MPPI_GD":
+            raise NotImplementedError
+        raise ValueError("unknown planner type: %s" % self.planner_type)
+
+    def _evaluate(self, model_out, act_seqs, state_cur):
+        return self.evaluate_traj(model_out["state_seqs"], act_seqs, state_cur=state_cur,
+                                  weights=model_out["weights"] if "weights" in model_out else None)
+
+    @torch.no_grad()
+    def trajectory_optimization_mppi(self, state_cur, act_seq):
+        """planner.py:234-277: n_update_iter rounds of sample -> rollout -> evaluate -> MPPI update; the best sampled
+        sequence over all rounds is returned (not the MPPI mean) and, with rollout_best, rolled out once more."""
+        model_outputs, eval_outputs = [], []
+        best_act_seq = best_reward = None
+        for i in range(self.n_update_iter):
+            if self.verbose:
+                print(f"chunk: {self.chunk_id}/{self.total_chunks}, iter: {i}/{self.n_update_iter}")
+            act_seqs = self.sample_action_sequences(act_seq, iter_index=i)
+            assert type(act_seqs) == torch.Tensor
+            assert act_seqs.shape == (self.n_sample, self.n_look_ahead, self.action_dim)
+            model_out = self.model_rollout(state_cur, act_seqs)
+            assert type(model_out["state_seqs"]) == torch.Tensor
+            eval_out = self._evaluate(model_out, act_seqs, state_cur)
+            reward_seqs = eval_out["reward_seqs"]
+            act_seq = self.optimize_action(act_seqs, reward_seqs)
+            top = torch.argmax(reward_seqs)
+            if i == 0 or reward_seqs[top] > best_reward:
+                best_act_seq, best_reward = act_seqs[top], reward_seqs[top]
+            if self.verbose:
+                model_outputs.append(model_out)
+                eval_outputs.append(eval_out)
+        act_seq = best_act_seq
+        best_model_out = best_eval_out = None
+        if self.rollout_best:
+            best_model_out = self.model_rollout(state_cur, act_seq.unsqueeze(0))
+            best_eval_out = self.evaluate_traj(best_model_out["state_seqs"], act_seq.unsqueeze(0), state_cur=state_cur)
+        return {"act_seq": act_seq,
+                "model_outputs": model_outputs if self.verbose else None,
+                "eval_outputs": eval_outputs if self.verbose else None,
+                "best_model_output": best_model_out,
+                "best_eval_output": best_eval_out}
+
+    def trajectory_optimization_gd(self, state_cur, act_seq):
+        raise NotImplementedError("planner_type 'GD' differentiates through the rollout; the HIP engine is inference-only")
+
+    def trajectory_optimization_mppi_gd(self, state_cur, act_seq=None):
+        pass
+
+    def merge_res(self, res_list):
+        """planner.py:311-323: the chunk whose winner scores best in its own batch-of-one re-evaluation."""
+        assert not self.verbose and self.rollout_best
+        scores = [res["best_eval_output"]["reward_seqs"].mean().item() for res in res_list]
+        win = res_list[int(np.argmax(scores))]
+        return {"act_seq": win["act_seq"], "model_outputs": None, "eval_outputs": None,
+                "best_model_output": win["best_model_output"], "best_eval_output": win["best_eval_output"]}
+
+    # ---------------------------------------------------------------------------------- all chunks in two rollout calls
+    @staticmethod
+    def _rows(out, lo, hi, total):
+        """rows [lo, hi) of every per-candidate tensor of a rollout / evaluation result"""
+        return {k: (v[lo:hi] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == total else v)
+                for k, v in out.items()}
+
+    @torch.no_grad()
+    def trajectory_optimization_chunked(self, state_cur, act_seq, n_chunk):
+        """The loop of plan.py:241-247 (`trajectory_optimization` per chunk, then `merge_res`) with one rollout call for
+        all chunks' candidates and one for the chunk winners; see the module docstring.  Needs planner_type 'MPPI',
+        n_update_iter == 1 (what plan.py configures), rollout_best and not verbose; anything else takes the loop."""
+        n_chunk = int(n_chunk)
+        assert type(state_cur) == torch.Tensor and type(act_seq) == torch.Tensor
+        assert act_seq.shape == (self.n_look_ahead, self.action_dim)
+        if self.planner_type != "MPPI" or self.n_update_iter != 1 or not self.rollout_best or self.verbose or n_chunk < 1:
+            res_all = []
+            for ci in range(n_chunk):
+                self.chunk_id = ci
+                res_all.append(self.trajectory_optimization(state_cur, act_seq))
+            return self.merge_res(res_all)
+        import torch.distributed as dist
+        from .sharding import shard_bounds, all_gather_costs
+        sharded = self.group is not None and dist.is_available() and dist.is_initialized()
+        pg = None if self.group in (None, True) else self.group
+        world = dist.get_world_size(pg) if sharded else 1
+        rank = dist.get_rank(pg) if sharded else 0
+        # every rank draws every chunk's samples, in the loop's order: the generator ends in the same state as after the
+        # reference's loop and the winners can be compared anywhere
+        samples = [self.sample_action_sequences(act_seq, iter_index=0) for _ in range(n_chunk)]
+        S, H, A = self.n_sample, self.n_look_ahead, self.action_dim
+        for s in samples:
+            assert type(s) == torch.Tensor and s.shape == (S, H, A)
+        c_lo, c_hi = shard_bounds(n_chunk, world, rank)
+        winners = torch.zeros((c_hi - c_lo, H, A), dtype=samples[0].dtype, device=samples[0].device)
+        if c_hi > c_lo:
+            mine = torch.cat(samples[c_lo:c_hi], dim=0)
+            model_out = self.model_rollout(state_cur, mine)
+            total = mine.shape[0]
+            for j in range(c_hi - c_lo):
+                part = self._rows(model_out, j * S, (j + 1) * S, total)
+                reward_seqs = self._evaluate(part, samples[c_lo + j], state_cur)["reward_seqs"]
+                assert reward_seqs.shape == (S,)
+                winners[j] = samples[c_lo + j][torch.argmax(reward_seqs)]
+        if world > 1:
+            k = H * A
+            bounds = [tuple(k * b for b in shard_bounds(n_chunk, world, r)) for r in range(world)]
+            winners = all_gather_costs(winners.reshape(-1).contiguous(), n_chunk * k, pg, bounds=bounds).reshape(n_chunk, H, A)
+        best_out = self.model_rollout(state_cur, winners)
+        res_all = []
+        for ci in range(n_chunk):
+            one = self._rows(best_out, ci, ci + 1, n_chunk)
+            ev = self.evaluate_traj(one["state_seqs"], winners[ci:ci + 1], state_cur=state_cur)
+            res_all.append({"act_seq": winners[ci], "model_outputs": None, "eval_outputs": None,
+                            "best_model_output": one, "best_eval_output": ev})
+        return self.merge_res(res_all)

@@ -433,7 +433,7 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5", "--planner"} & set(sys.argv)):
     main()
 
 # dynamics_masked for the other two materials: gripper offset + connect_tools_all (cloth) and the 5-point pusher
@@ -815,3 +815,75 @@ def gen_forward_nhis5_case(name, refs):
 
 if __name__ == "__main__" and "--nhis5" in sys.argv:
     gen_forward_nhis5_case("forward_softbody_nhis5", import_reference())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Row (f) rank 2 of SURVEY §8, host side: the Planner class (src/planning/real_world/planner.py:38-323, torch + numpy
+# only).  The rollout and cost callables are small closed-form stand-ins defined in tests/helpers.py (toy_rollout /
+# toy_cost, shared with the tests), so the fixture pins the class logic: sampling defaults, the MPPI loop and its
+# best-candidate rule, rollout_best, merge_res over chunks.
+def gen_planner_case(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_planner", f"{REF}/planning/real_world/planner.py")
+    RP = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(RP)
+    sys.path.insert(0, os.path.dirname(OUT))
+    from helpers import toy_rollout, toy_cost, toy_planner_config
+    import contextlib, io
+    store = {}
+    cfg = toy_planner_config(toy_rollout, toy_cost)
+    # (a) the class defaults: filtered-normal sampler, clamp, softmax mean; 3 update iterations
+    pl = RP.Planner(dict(cfg))
+    pl.sample_action_sequences = lambda a, iter_index=None: pl.sample_action_sequences_default(a)   # the MPPI loop passes iter_index
+    torch.manual_seed(31)
+    act0 = torch.rand(cfg["n_look_ahead"], cfg["action_dim"]) * (cfg["action_upper_lim"] - cfg["action_lower_lim"]) + cfg["action_lower_lim"]
+    state_cur = torch.linspace(-1, 1, 12).reshape(4, 3)
+    store["act0"], store["state_cur"] = act0.numpy(), state_cur.numpy()
+    torch.manual_seed(32)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = pl.trajectory_optimization(state_cur, act0.clone())
+    store["a_act_seq"] = res["act_seq"].numpy()
+    store["a_best_state"] = res["best_model_output"]["state_seqs"].numpy()
+    store["a_best_reward"] = res["best_eval_output"]["reward_seqs"].numpy()
+    torch.manual_seed(33)
+    store["a_sample"] = pl.sample_action_sequences_default(act0.clone()).numpy()
+    torch.manual_seed(34)
+    rew = torch.randn(cfg["n_sample"])
+    store["a_rewards"] = rew.numpy()
+    store["a_mppi_mean"] = pl.optimize_action_mppi_default(torch.from_numpy(store["a_sample"]).clone(), rew).numpy()
+    # (b) verbose: every iteration's outputs are kept
+    cfgv = dict(cfg); cfgv["verbose"] = True; cfgv["n_update_iter"] = 2
+    pv = RP.Planner(cfgv)
+    pv.sample_action_sequences = lambda a, iter_index=None: pv.sample_action_sequences_default(a)
+    torch.manual_seed(35)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rv = pv.trajectory_optimization(state_cur, act0.clone())
+    store["b_act_seq"] = rv["act_seq"].numpy()
+    store["b_rewards"] = np.stack([e["reward_seqs"].numpy() for e in rv["eval_outputs"]])
+    # (c) fps sampling on a small 2-d action box
+    cfgf = toy_planner_config(toy_rollout, toy_cost, action_dim=2, noise_type="fps", n_sample=9, n_update_iter=1)
+    cfgf["action_lower_lim"] = torch.tensor([0.0, -0.1]); cfgf["action_upper_lim"] = torch.tensor([0.2, 0.1])
+    pf = RP.Planner(cfgf)
+    store["c_fps"] = pf.sample_action_sequences_default(torch.zeros(cfgf["n_look_ahead"], 2)).numpy()
+    # (d) the chunk loop of plan.py:241-247: 5 chunks from the same nominal sequence, then merge_res
+    cfgc = dict(cfg); cfgc["n_update_iter"] = 1
+    pc = RP.Planner(cfgc)
+    pc.sample_action_sequences = lambda a, iter_index=None: pc.sample_action_sequences_default(a)
+    torch.manual_seed(36)
+    res_all = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for ci in range(5):
+            pc.chunk_id = ci
+            r = pc.trajectory_optimization(state_cur, act0.clone())
+            res_all.append({k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in r.items()})
+        merged = pc.merge_res(res_all)
+    store["d_chunk_act_seqs"] = np.stack([r["act_seq"].numpy() for r in res_all])
+    store["d_chunk_scores"] = np.array([r["best_eval_output"]["reward_seqs"].mean().item() for r in res_all])
+    store["d_act_seq"] = merged["act_seq"].numpy()
+    store["d_best_reward"] = merged["best_eval_output"]["reward_seqs"].numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+    print(f"{name}: chunk scores {store['d_chunk_scores']}, merged act {store['d_act_seq'][0]}")
+
+
+if __name__ == "__main__" and "--planner" in sys.argv:
+    gen_planner_case("planner")

@@ -28,3 +28,38 @@ def golden_step_index(repeat):
     repeat = np.atleast_2d(repeat)
     mx = repeat.max(0)
     return np.concatenate([[0], np.cumsum(mx)])[:-1]
+
+
+# ---- closed-form stand-ins for the two callables a Planner is configured with (planner.py:47-61); shared by
+# tests/golden/make_golden.py --planner (which drives the REFERENCE Planner with them) and tests/test_planner.py
+def toy_rollout(state_cur, act_seqs):
+    """state_cur (P,3), act_seqs (S,H,A) -> {'state_seqs': (S,H,P,3)}: the cloud shifted by the running sum of the first
+    two action components (x, z) and tilted by the third, per candidate - independent of the rest of the batch."""
+    import torch
+    shift = torch.cumsum(act_seqs[..., :2], dim=1)                                   # (S,H,2)
+    s = state_cur[None, None].repeat(act_seqs.shape[0], act_seqs.shape[1], 1, 1).clone()
+    s[..., 0] += shift[..., 0, None]
+    s[..., 2] += shift[..., 1, None]
+    if act_seqs.shape[-1] > 2:
+        s[..., 1] += 0.1 * torch.sin(act_seqs[..., 2])[..., None] * state_cur[None, None, :, 0]
+    return {"state_seqs": s, "action_seqs": act_seqs}
+
+
+def toy_cost(state_seqs, act_seqs, state_cur=None, weights=None, **kw):
+    """-> {'reward_seqs': (S,)}: distance of the final cloud centre to a target, scaled by the batch maximum (the
+    batch-global normalisation of running_cost, plan.py:37) plus an action-length term."""
+    import torch
+    target = torch.tensor([0.4, 0.0, -0.3])
+    err = (state_seqs.mean(2) - target).norm(dim=-1)                                   # (S,H)
+    w = 2.0 / (err.max() + 1e-6)
+    return {"reward_seqs": -w * err[:, -1] - 0.05 * act_seqs.abs().sum((1, 2))}
+
+
+def toy_planner_config(rollout, cost, action_dim=3, n_sample=16, n_update_iter=3, noise_type="normal"):
+    import torch
+    return {"action_dim": action_dim, "model_rollout_fn": rollout, "evaluate_traj_fn": cost, "n_sample": n_sample,
+            "n_look_ahead": 3, "n_update_iter": n_update_iter, "reward_weight": 20.0,
+            "action_lower_lim": torch.tensor([-0.5, -0.4, -1.0][:action_dim]),
+            "action_upper_lim": torch.tensor([0.5, 0.6, 1.0][:action_dim]),
+            "planner_type": "MPPI", "device": "cpu", "verbose": False, "noise_type": noise_type, "noise_level": 0.2,
+            "rollout_best": True}

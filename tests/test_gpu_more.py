@@ -716,3 +716,64 @@ def test_edge_block_schedule_equals_row_schedule_bitwise(ag, dev, N_o, M, topk, 
     for b in range(B):
         assert np.array_equal(out["blocks"][1][b, :n[b]], out["rows"][1][b, :n[b]]), b
         assert np.array_equal(out["blocks"][2][b, :n[b]], out["rows"][2][b, :n[b]]), b
+
+
+def test_planner_class_chunk_loop_equals_chunked_entry_on_the_engine(ag, O, dev):
+    """The reference's planning loop (plan.py:177-247): a Planner configured with dynamics / running_cost / the MPPI
+    helpers, called once per chunk of n_sample_chunk candidates, merged with merge_res.  Planner.trajectory_optimization_chunked
+    does the same with one rollout call for all chunks and one for the winners - bit-identical result (a candidate's rollout
+    does not depend on its batch), identical generator state afterwards."""
+    from functools import partial
+    from adaptigraph_amd.planner import Planner
+    rng = np.random.default_rng(21)
+    task = _task("rope")
+    W, m = _model(ag, O, "rope", 21, dev)
+    cloud = _rope(100, rng)
+    s0 = torch.from_numpy(cloud).to(dev)
+    ppm = _ppm(task, "rope")
+    lo = torch.tensor([cloud[:, 0].min() - 0.3, cloud[:, 2].min() - 0.3, -3.14, 2.0], device=dev)
+    hi = torch.tensor([cloud[:, 0].max() + 0.3, cloud[:, 2].max() + 0.3, 3.14, 4.0], device=dev)
+    target = torch.from_numpy(cloud + np.float32([0.2, 0, 0.1])).to(dev)
+    S, n_chunk, H = 24, 4, 2
+    calls = []
+
+    def rollout(state_cur, act_seqs):
+        calls.append(int(act_seqs.shape[0]))
+        return ag.dynamics(state_cur, act_seqs, model=m, device=dev, ppm_optimizer=ppm)
+
+    cfg = {"action_dim": 4, "model_rollout_fn": rollout,
+           "evaluate_traj_fn": partial(ag.running_cost, error_func=partial(ag.chamfer, y=target[None]),
+                                       penalty_func=partial(ag.rope_penalty, sim_real_ratio=10.0),
+                                       bbox=np.array([[-4.5, 0.0], [-2.5, 4.5]])),
+           "sampling_action_seq_fn": partial(ag.sample_action_seq, action_lower_lim=lo, action_upper_lim=hi, n_sample=S,
+                                             device=dev, noise_level=0.3, push_length=task["push_length"]),
+           "clip_action_seq_fn": partial(ag.clip_actions, action_lower_lim=lo, action_upper_lim=hi),
+           "optimize_action_mppi_fn": partial(ag.optimize_action_mppi, reward_weight=500.0, action_lower_lim=lo,
+                                              action_upper_lim=hi, push_length=task["push_length"]),
+           "n_sample": S, "n_look_ahead": H, "n_update_iter": 1, "reward_weight": 500.0, "action_lower_lim": lo,
+           "action_upper_lim": hi, "planner_type": "MPPI", "device": dev, "verbose": False, "noise_level": 0.3,
+           "rollout_best": True}
+    planner = Planner(cfg)
+    torch.manual_seed(3)
+    act_seq = torch.rand((H, 4), device=dev) * (hi - lo) + lo
+    torch.manual_seed(4)
+    res_all = []
+    for ci in range(n_chunk):                                           # plan.py:241-247
+        planner.chunk_id = ci
+        res = planner.trajectory_optimization(s0, act_seq)
+        res_all.append({k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in res.items()})
+    loop = planner.merge_res(res_all)
+    gen_after_loop = torch.cuda.get_rng_state(dev)
+    assert calls == [S, 1] * n_chunk
+    calls.clear()
+    torch.manual_seed(4)
+    fused = planner.trajectory_optimization_chunked(s0, act_seq, n_chunk)
+    assert calls == [S * n_chunk, n_chunk]
+    assert torch.equal(torch.cuda.get_rng_state(dev), gen_after_loop)
+    assert torch.equal(fused["act_seq"], loop["act_seq"])
+    assert torch.equal(fused["best_model_output"]["state_seqs"], loop["best_model_output"]["state_seqs"])
+    assert torch.equal(fused["best_eval_output"]["reward_seqs"], loop["best_eval_output"]["reward_seqs"])
+    assert fused["best_model_output"]["state_seqs"].shape == (1, H, 100, 3)
+    # the winner against the oracle
+    want = O.dynamics(W, 3, cloud, loop["act_seq"].cpu().numpy()[None], task)["state_seqs"]
+    assert np.abs(loop["best_model_output"]["state_seqs"].cpu().numpy() - want).max() <= POS_TOL

@@ -1,0 +1,153 @@
+"""SURVEY §8(f) rank 2, host side: adaptigraph_amd.planner.Planner against vectors recorded from the reference's Planner
+(src/planning/real_world/planner.py:38-323) driven with the closed-form rollout / cost stand-ins of tests/helpers.py
+(tests/golden/make_golden.py --planner).  Pure host logic: runs on CPU tensors, no engine involved.
+
+Bit-exact: the class only samples (same torch calls in the same order), calls the two callables, and takes argmax /
+softmax means with the same torch operations as the reference.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, toy_rollout, toy_cost, toy_planner_config
+from adaptigraph_amd.planner import Planner, farthest_points
+
+
+def _planner(**over):
+    cfg = toy_planner_config(toy_rollout, toy_cost)
+    cfg.update(over)
+    pl = Planner(cfg)
+    pl.sample_action_sequences = lambda a, iter_index=None: pl.sample_action_sequences_default(a)
+    return pl
+
+
+def test_mppi_loop_defaults_match_reference():
+    g = load_golden("planner")
+    pl = _planner()
+    act0, state_cur = torch.from_numpy(g["act0"]), torch.from_numpy(g["state_cur"])
+    torch.manual_seed(32)
+    res = pl.trajectory_optimization(state_cur, act0.clone())
+    assert np.array_equal(res["act_seq"].numpy(), g["a_act_seq"])
+    assert np.array_equal(res["best_model_output"]["state_seqs"].numpy(), g["a_best_state"])
+    assert np.array_equal(res["best_eval_output"]["reward_seqs"].numpy(), g["a_best_reward"])
+    assert res["model_outputs"] is None and res["eval_outputs"] is None
+    torch.manual_seed(33)
+    assert np.array_equal(pl.sample_action_sequences_default(act0.clone()).numpy(), g["a_sample"])
+    mean = pl.optimize_action_mppi_default(torch.from_numpy(g["a_sample"]).clone(), torch.from_numpy(g["a_rewards"]))
+    assert np.array_equal(mean.numpy(), g["a_mppi_mean"])
+    x = torch.tensor([[9.0, -9.0, 0.3]])
+    assert pl.clip_actions_default(x) is x and x.tolist() == [[0.5, -0.4000000059604645, 0.30000001192092896]]
+
+
+def test_verbose_keeps_every_iteration():
+    g = load_golden("planner")
+    pl = _planner(verbose=True, n_update_iter=2)
+    torch.manual_seed(35)
+    res = pl.trajectory_optimization(torch.from_numpy(g["state_cur"]), torch.from_numpy(g["act0"]).clone())
+    assert np.array_equal(res["act_seq"].numpy(), g["b_act_seq"])
+    assert len(res["model_outputs"]) == 2 and len(res["eval_outputs"]) == 2
+    assert np.array_equal(np.stack([e["reward_seqs"].numpy() for e in res["eval_outputs"]]), g["b_rewards"])
+
+
+def test_fps_sampler_matches_reference():
+    g = load_golden("planner")
+    cfg = toy_planner_config(toy_rollout, toy_cost, action_dim=2, noise_type="fps", n_sample=9, n_update_iter=1)
+    cfg["action_lower_lim"], cfg["action_upper_lim"] = torch.tensor([0.0, -0.1]), torch.tensor([0.2, 0.1])
+    pl = Planner(cfg)
+    assert np.array_equal(pl.sample_action_sequences_default(torch.zeros(3, 2)).numpy(), g["c_fps"])
+    pts = np.array([[0.0, 0, 1, 0], [0, 0, 0, 0], [5, 5, 5, 5], [0, 0, 3, 0]], np.float64)
+    assert np.array_equal(farthest_points(pts, 2), pts[[3, 2]])             # starts at the largest half-to-half motion
+    assert np.array_equal(farthest_points(pts, 2, init_idx=1), pts[[1, 2]])
+
+
+def test_chunk_loop_and_merge_match_reference_and_chunked_entry_equals_loop():
+    g = load_golden("planner")
+    act0, state_cur = torch.from_numpy(g["act0"]), torch.from_numpy(g["state_cur"])
+    pl = _planner(n_update_iter=1)
+    torch.manual_seed(36)
+    res_all = []
+    for ci in range(5):
+        pl.chunk_id = ci
+        res_all.append(pl.trajectory_optimization(state_cur, act0.clone()))
+    merged = pl.merge_res(res_all)
+    assert np.array_equal(np.stack([r["act_seq"].numpy() for r in res_all]), g["d_chunk_act_seqs"])
+    assert np.array_equal(np.array([r["best_eval_output"]["reward_seqs"].mean().item() for r in res_all]), g["d_chunk_scores"])
+    assert np.array_equal(merged["act_seq"].numpy(), g["d_act_seq"])
+    assert np.array_equal(merged["best_eval_output"]["reward_seqs"].numpy(), g["d_best_reward"])
+    end_state = torch.get_rng_state()
+    # one rollout call for all chunks + one for the winners: same winner, same outputs, generator left in the same state
+    calls = []
+    pl2 = _planner(n_update_iter=1, model_rollout_fn=lambda s, a: (calls.append(a.shape[0]), toy_rollout(s, a))[1])
+    torch.manual_seed(36)
+    fused = pl2.trajectory_optimization_chunked(state_cur, act0.clone(), 5)
+    assert calls == [5 * 16, 5]
+    assert torch.equal(torch.get_rng_state(), end_state)
+    assert np.array_equal(fused["act_seq"].numpy(), g["d_act_seq"])
+    assert np.array_equal(fused["best_eval_output"]["reward_seqs"].numpy(), g["d_best_reward"])
+    assert torch.equal(fused["best_model_output"]["state_seqs"], merged["best_model_output"]["state_seqs"])
+    # configurations the fused entry does not cover fall back to the loop
+    pl3 = _planner(n_update_iter=2)
+    torch.manual_seed(5)
+    a = pl3.trajectory_optimization_chunked(state_cur, act0.clone(), 2)
+    torch.manual_seed(5)
+    b = pl3.merge_res([pl3.trajectory_optimization(state_cur, act0.clone()) for _ in range(2)])
+    assert torch.equal(a["act_seq"], b["act_seq"])
+
+
+def test_config_validation_and_gd():
+    cfg = toy_planner_config(toy_rollout, toy_cost)
+    bad = dict(cfg); bad.pop("n_sample")
+    with pytest.raises(KeyError):
+        Planner(bad)
+    bad = dict(cfg); bad["planner_type"] = "CEM"
+    with pytest.raises(AssertionError):
+        Planner(bad)
+    bad = dict(cfg); bad["action_lower_lim"] = torch.zeros(2)
+    with pytest.raises(AssertionError):
+        Planner(bad)
+    gd = dict(cfg); gd["planner_type"] = "GD"
+    with pytest.raises(NotImplementedError):
+        Planner(gd).trajectory_optimization(torch.zeros(4, 3), torch.zeros(3, 3))
+    with pytest.raises(AssertionError):
+        Planner(cfg).trajectory_optimization(torch.zeros(4, 3), torch.zeros(2, 3))      # wrong horizon
+
+
+# ------------------------------------------------------------------------------------------------- chunks over 2 ranks
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _chunk_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_golden("planner")
+    act0, state_cur = torch.from_numpy(g["act0"]), torch.from_numpy(g["state_cur"])
+    calls = []
+    pl = _planner(n_update_iter=1, group=True, model_rollout_fn=lambda s, a: (calls.append(a.shape[0]), toy_rollout(s, a))[1])
+    torch.manual_seed(36)
+    res = pl.trajectory_optimization_chunked(state_cur, act0.clone(), 5)          # 3 + 2 chunks
+    ok = np.array_equal(res["act_seq"].numpy(), g["d_act_seq"]) and \
+        np.array_equal(res["best_eval_output"]["reward_seqs"].numpy(), g["d_best_reward"])
+    q.put((rank, bool(ok), calls))
+    dist.destroy_process_group()
+
+
+def test_chunks_dealt_to_two_gloo_ranks_give_the_reference_result():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, [3 * 16, 5]), (1, True, [2 * 16, 5])]
