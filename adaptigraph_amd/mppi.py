@@ -106,8 +106,9 @@ def mpc_iteration(state_cur, act_seq, model_rollout_fn, evaluate_traj_fn, action
     model_rollout_fn(state_cur, act_seqs) and evaluate_traj_fn(state_seqs, act_seqs, state_cur=...) are the same
     partials plan.py builds (plan.py:175, 190).  `group`: shard the candidates over the ranks of that group; every
     rank must call with the same generator state (or pass the same `act_seqs`, which then serves the first iteration).
-    The whole candidate batch goes through one rollout call (the engine chunks on the device): the reference's
-    host-side loop over n_sample / n_sample_chunk chunks and its merge_res (plan.py:241-247) have nothing left to do."""
+    The whole candidate batch goes through one rollout call (the engine chunks on the device) and the cost maxima are
+    taken over the whole batch; the reference's loop over n_sample / n_sample_chunk chunks with its chunk-local maxima
+    and merge_res (plan.py:241-247) is planner.Planner.trajectory_optimization_chunked."""
     from .sharding import shard_bounds, all_gather_costs
     import torch.distributed as dist
     pg = None if group in (None, True) else group

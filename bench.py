@@ -330,6 +330,8 @@ def main():
             if not os.path.exists(tpath):
                 return None
             tj = json.load(open(tpath))
+            if key not in tj or "hbm_bytes_per_launch" not in tj:
+                return None
             return tj["hbm_bytes_per_launch"] if abs(tj[key] - want) <= 0.01 * want else None
 
         traffic = pmc_traffic("r02_traffic_k_edge_enc.json", "edges_per_launch", edges_per_launch)
