@@ -232,8 +232,8 @@ def main():
     assert torch.isfinite(costs).all()
     # candidates of the timed batch that the CPU leg re-computes with the oracle: first, last and evenly spaced ones
     # (every launch chunk of both streams is hit); their GPU results come from the LAST TIMED step
-    # three candidates per worker core (16-core CPU share of a one-GPU box): ~10 s of CPU work
-    n_pick = 0 if args.no_cpu_baseline or world > 1 else max(2, min(3 * min(16, os.cpu_count() or 2), hi - lo))
+    # four candidates per worker core (16-core CPU share of a one-GPU box): ~12 s of CPU work
+    n_pick = 0 if args.no_cpu_baseline or world > 1 else max(2, min(4 * min(16, os.cpu_count() or 2), hi - lo))
     picks = sorted({int(round(i * (hi - lo - 1) / max(1, n_pick - 1))) for i in range(n_pick)})
     timed_seqs = last["seq"][picks].cpu().numpy() if picks else None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
