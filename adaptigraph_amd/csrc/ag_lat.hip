@@ -271,25 +271,41 @@ __device__ __forceinline__ void gather_sweep(const NDev& g, const PassRow& r, bo
     const float* up = g.Uin + urow * (unsigned)NFP + 32 * T0 + 4 * c;
 #pragma unroll
     for (int t = 0; t < NTL; ++t) { u[t] = *reinterpret_cast<const f32x4*>(up + 32 * t); acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int k = 0; k < kmax; ++k) {
-        const bool on = k < r.deg;
-        int sj;
-        if (k < 16) sj = __shfl(k < 8 ? idx0 : idx1, (lane & 56) + (k & 7), 64);     // k is wave-uniform
-        else sj = on ? snd[k] : r.i;
-        const unsigned crow = (!on || (g.dedupe && sj == r.i)) ? selfrow : cb + (unsigned)k;
-        const unsigned vrow = cls ? (sj >= (int)N_o ? tool0 + (unsigned)sj : (unsigned)sj) : vb + (unsigned)sj;
-        const float* cp = g.C + crow * (unsigned)NFP + 32 * T0 + 4 * c;
-        const float* vp = g.Vin + vrow * (unsigned)NFP + 32 * T0 + 4 * c;
-        f32x4 cv[NTL], vv[NTL];
+    // four edges per trip: their 8 * NTL loads are issued together (a single small graph is latency-bound: one edge per
+    // trip made the row's edges a chain of ~0.7-us round trips), then summed in CSR order - same additions, same bits.
+    // Edges past the row's (or the wave's) last one read the self-loop constant row / the row's own V row: valid
+    // addresses, values unused.
+    constexpr int EB = 4;
+    for (int k0 = 0; k0 < kmax; k0 += EB) {
+        f32x4 cv[EB][NTL], vv[EB][NTL];
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) { cv[t] = *reinterpret_cast<const f32x4*>(cp + 32 * t); vv[t] = *reinterpret_cast<const f32x4*>(vp + 32 * t); }
+        for (int q = 0; q < EB; ++q) {
+            const int k = k0 + q;                                            // wave-uniform
+            const bool on = k < r.deg;
+            int sj;
+            if (k < 16) sj = __shfl(k < 8 ? idx0 : idx1, (lane & 56) + (k & 7), 64);
+            else sj = on ? snd[k] : r.i;
+            const unsigned crow = (!on || (g.dedupe && sj == r.i)) ? selfrow : cb + (unsigned)k;
+            const unsigned vrow = cls ? (sj >= (int)N_o ? tool0 + (unsigned)sj : (unsigned)sj) : vb + (unsigned)sj;
+            const float* cp = g.C + crow * (unsigned)NFP + 32 * T0 + 4 * c;
+            const float* vp = g.Vin + vrow * (unsigned)NFP + 32 * T0 + 4 * c;
 #pragma unroll
-        for (int t = 0; t < NTL; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float m = fmaxf((cv[t][e] + u[t][e]) + vv[t][e], 0.0f);
-                acc[t][e] += on ? m : 0.0f;
+            for (int t = 0; t < NTL; ++t) {
+                cv[q][t] = *reinterpret_cast<const f32x4*>(cp + 32 * t);
+                vv[q][t] = *reinterpret_cast<const f32x4*>(vp + 32 * t);
             }
+        }
+#pragma unroll
+        for (int q = 0; q < EB; ++q) {
+            const bool on = k0 + q < r.deg;
+#pragma unroll
+            for (int t = 0; t < NTL; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float m = fmaxf((cv[q][t][e] + u[t][e]) + vv[q][t][e], 0.0f);
+                    acc[t][e] += on ? m : 0.0f;
+                }
+        }
     }
     float* wp = img_rows8 + rr * IMG_PITCH + 32 * T0 + 4 * c;
 #pragma unroll
