@@ -278,6 +278,7 @@ struct GDev {
     // first round of a rollout step, else what the previous round's chain wrote) - never the buffers this launch writes
     const float* Uin; const float* Vin; const int* deg; int ell_stride; int dedupe; unsigned self_row; const int* n_guard;
     int stagger_ticks; unsigned first_wave;   // see stagger_second_workgroup
+    unsigned n_tiles;                         // k_edge_enc: > 0 = persistent workgroups (AG_ENC_PERSIST) over this many tiles
     // ragged batches (masked rollouts): the propagate chains walk a compact list of the rows that exist - valid object
     // particles and tools, plus one phantom candidate that stands for every masked-out particle (GraphBufs) - instead of
     // all B*N rows; rowlist[slot] = dense row b*N + i, *n_rows = number of slots.  Null: every dense row, in order.
@@ -530,18 +531,30 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
     // with candidate-major order every candidate's early-exit tail (tiles past its edge count) lands on the same
     // engines and the others carry all the work (measured: 16.7 % fewer rows, same kernel time).  Tile-major puts
     // every early-exit workgroup at the end of the grid.
-    const int b = (int)(blockIdx.x % (unsigned)g.B);
-    const int e0 = (int)(blockIdx.x / (unsigned)g.B) * WG_ROWS;
+    // Tile loop.  By default the grid has one workgroup per tile and the loop runs once; AG_ENC_PERSIST=n launches n
+    // persistent workgroups that walk the tiles blk, blk + n, ... instead (measured: no faster alone - 1.525 vs 1.50 ms per
+    // launch - and worse beside other streams, whose kernels can then only enter at this kernel's end).  The loop FORM is
+    // kept for what it does to hipcc's code: with the tile body inside a loop whose trip count it cannot see, and the
+    // weight base made opaque per tile (or the 40 DMA piece addresses are hoisted into the preheader and spill: 106
+    // VGPRs), the kernel comes out 1.4 % faster than the straight-line version (A/B on the same box, twice on three
+    // boxes: 1.526 -> 1.504 ms per launch; 212 instead of 206 VGPRs, no scratch).
+    const unsigned n_tiles = g.n_tiles ? g.n_tiles : gridDim.x;
+    for (unsigned blk = blockIdx.x; blk < n_tiles; blk += gridDim.x) {
+    int zi = 0;
+    asm volatile("" : "+s"(zi));                           // per-tile opaque zero (see above)
+    const float* const wts = g.w + zi;
+    const int b = (int)(blk % (unsigned)g.B);
+    const int e0 = (int)(blk / (unsigned)g.B) * WG_ROWS;
     const int ne = g.n_ns ? g.n_ns[b] : g.n_edges[b];       // rows to encode: all edges, or the non-self-loop ones
-    if (e0 >= ne) return;                                    // whole workgroup past this candidate's edges
+    if (e0 >= ne) continue;                                  // whole workgroup past this candidate's edges
     if (g.dbg && tid == 0) {
-        g.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
-        g.dbg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        g.dbg[blk * 4 + 0] = __builtin_amdgcn_s_memtime();
+        g.dbg[blk * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
 
     // small first-layer panel -> buffer 1; under its MFMAs, L2 half 0 -> buffer 0
-    stage_now<EDGE_L1_CHUNKS * CHUNK_FLOATS_MB5>(lds + BUF_FLOATS, g.w + WL::E_L1, tid);
-    dma_copy<Q_FLOATS>(lds, g.w + WL::E_L2, tid);            // lands under the feature gather and the L1 sweep
+    stage_now<EDGE_L1_CHUNKS * CHUNK_FLOATS_MB5>(lds + BUF_FLOATS, wts + WL::E_L1, tid);
+    dma_copy<Q_FLOATS>(lds, wts + WL::E_L2, tid);            // lands under the feature gather and the L1 sweep
 
     const int t = e0 + wave * 32 + (lane & 31);
     const bool valid = t < ne;
@@ -573,15 +586,17 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
     mma_feat<EDGE_L1_CHUNKS, (RD + 2) / 2>(lds + BUF_FLOATS, f, y.t, lane);     // RD inputs + bias: 9 (n_his 4) / 11 steps of 12
     __syncthreads();
     relu_one(y, lane);
-    layer160<Q_FLOATS>(lds, g.w + WL::E_L2, g.w + WL::E_L3, y, x, tid, lane);
+    layer160<Q_FLOATS>(lds, wts + WL::E_L2, wts + WL::E_L3, y, x, tid, lane);
     relu_one(x, lane);
-    layer160<Q_FLOATS>(lds, g.w + WL::E_L3, g.w + WL::E_W1, x, y, tid, lane);
+    layer160<Q_FLOATS>(lds, wts + WL::E_L3, wts + WL::E_W1, x, y, tid, lane);
     relu_one(y, lane);
-    layer160<0>(lds, g.w + WL::E_W1, nullptr, y, x, tid, lane);
+    layer160<0>(lds, wts + WL::E_W1, nullptr, y, x, tid, lane);
     store_rows_t(x, g.C, (int)((long)b * g.c_cap + el), valid, stg, lane);
     if (g.dbg && tid == 0) {
-        g.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
-        g.dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        g.dbg[blk * 4 + 2] = __builtin_amdgcn_s_memtime();
+        g.dbg[blk * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+    __syncthreads();                                         // the weight buffers are restaged by the next tile
     }
 }
 
@@ -1024,7 +1039,7 @@ static GDev to_dev(const float* w, const GraphBufs& g) {
     d.w = w; d.node_in = g.node_in; d.feat12 = g.feat12; d.group = g.group; d.eff = g.eff; d.P = g.P; d.U = g.UV[1][0];
     d.V = g.UV[1][1];; d.C = g.C; d.recv = g.recv; d.send = g.send; d.row_ptr = g.row_ptr;
     d.n_edges = g.n_edges; d.B = g.B; d.N = g.N; d.n_p = g.n_p; d.n_inst = g.n_inst; d.edge_cap = g.edge_cap;
-    d.c_cap = g.c_cap; d.clamp = 0; d.pred_pos = nullptr; d.pred_motion = nullptr;
+    d.c_cap = g.c_cap; d.clamp = 0; d.pred_pos = nullptr; d.pred_motion = nullptr; d.n_tiles = 0;
     d.cls_on = g.cls_on; d.N_o = g.N_o; d.M = g.M; d.first_round = 0; d.vmask = g.vmask; d.c_eff = g.c_eff; d.c_P = g.c_P;
     d.row0 = 0; d.nrows = (long)g.B * g.N;
     d.ns_edge = g.ns_edge; d.n_ns = g.n_ns;
@@ -1061,7 +1076,12 @@ hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
     }
     if (d.wb3) hipLaunchKernelGGL(k_edge_enc_b3, dim3((unsigned)(rows / WGB_ROWS)), dim3(WGB), 0, st, d);
     else if (g.n_his == 5) hipLaunchKernelGGL(k_edge_enc<5>, dim3(nwg), dim3(WG), 0, st, d);
-    else hipLaunchKernelGGL(k_edge_enc<4>, dim3(nwg), dim3(WG), 0, st, d);
+    else {
+        static const int persist = getenv("AG_ENC_PERSIST") ? atoi(getenv("AG_ENC_PERSIST")) : 0;
+        unsigned grid = nwg;
+        if (persist > 0 && probe_left <= 0 && nwg > (unsigned)persist) { d.n_tiles = nwg; grid = (unsigned)persist; }
+        hipLaunchKernelGGL(k_edge_enc<4>, dim3(grid), dim3(WG), 0, st, d);
+    }
     if (probe_left > 0) {
         --probe_left;
         (void)hipStreamSynchronize(st);
