@@ -1077,7 +1077,8 @@ hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
     if (d.wb3) hipLaunchKernelGGL(k_edge_enc_b3, dim3((unsigned)(rows / WGB_ROWS)), dim3(WGB), 0, st, d);
     else if (g.n_his == 5) hipLaunchKernelGGL(k_edge_enc<5>, dim3(nwg), dim3(WG), 0, st, d);
     else {
-        static const int persist = getenv("AG_ENC_PERSIST") ? atoi(getenv("AG_ENC_PERSIST")) : 0;
+        const char* pe = getenv("AG_ENC_PERSIST");                             // read per call (tests toggle it)
+        const int persist = pe ? atoi(pe) : 0;
         unsigned grid = nwg;
         if (persist > 0 && probe_left <= 0 && nwg > (unsigned)persist) { d.n_tiles = nwg; grid = (unsigned)persist; }
         hipLaunchKernelGGL(k_edge_enc<4>, dim3(grid), dim3(WG), 0, st, d);

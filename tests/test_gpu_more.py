@@ -777,3 +777,28 @@ def test_planner_class_chunk_loop_equals_chunked_entry_on_the_engine(ag, O, dev)
     # the winner against the oracle
     want = O.dynamics(W, 3, cloud, loop["act_seq"].cpu().numpy()[None], task)["state_seqs"]
     assert np.abs(loop["best_model_output"]["state_seqs"].cpu().numpy() - want).max() <= POS_TOL
+
+
+def test_edge_chain_persistent_workgroups_equal_one_workgroup_per_tile_bitwise(ag, O, dev):
+    """AG_ENC_PERSIST=n runs k_edge_enc with n persistent workgroups walking the tiles (a measured-and-documented knob,
+    DESIGN.md section 3.1); rows are independent columns of the MFMA, so the result must not change - also when n does not
+    divide the tile count and some workgroups get one tile more."""
+    import os
+    rng = np.random.default_rng(81)
+    task = _task("cloth")
+    W, m = _model(ag, O, "cloth", 81, dev)
+    cloud = _grid(20, 0.3, 0.02, rng)
+    a = torch.from_numpy(_actions(cloud, 12, 2, [[2, 1]] * 12, rng)).to(dev)
+    s0 = torch.from_numpy(cloud).to(dev)
+    os.environ["AG_LATENCY"] = "0"                                       # throughput chains at this size
+    try:
+        ref = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"]
+        for n in ("7", "64"):
+            os.environ["AG_ENC_PERSIST"] = n
+            try:
+                got = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"]
+            finally:
+                del os.environ["AG_ENC_PERSIST"]
+            assert torch.isfinite(got).all() and torch.equal(got, ref), n
+    finally:
+        del os.environ["AG_LATENCY"]
