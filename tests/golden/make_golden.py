@@ -433,7 +433,7 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5", "--planner"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5", "--planner", "--fullsize"} & set(sys.argv)):
     main()
 
 # dynamics_masked for the other two materials: gripper offset + connect_tools_all (cloth) and the 5-point pusher
@@ -887,3 +887,89 @@ def gen_planner_case(name):
 
 if __name__ == "__main__" and "--planner" in sys.argv:
     gen_planner_case("planner")
+
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The headline sizes, run through the REAL reference (r03): cloth 45 x 45 (+1 gripper particle) and granular 32 x 32
+# (+5 pusher particles), 20 free-running rollout steps (2 look-ahead x repeat 10), the inputs bench.py /
+# tools/bench_configs.py time (same cloud, weights, action batch: candidates of the timed 1024-candidate batch, incl. two
+# whose GPU rollout left the oracle's after a near-tie in BENCH_r02).  The dense reference needs ~0.35 GB per cloth
+# candidate, so a handful of candidates is what it can do here.  Stored per forward: the edge list (int16 pairs + a
+# SHA-256 over the int32 lists), the prediction, the tool particles' positions; state_seqs.  Each file < 4 MB.
+def gen_fullsize(name, material, cloud, action, W, task_over, refs, cand_ids):
+    import hashlib
+    DynamicsPredictor, _, dynamics, _ = refs
+    dyn, task = load_cfg(material)
+    task = dict(task)
+    task.update(task_over)
+    model = make_model(DynamicsPredictor, dyn, 0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    ppm = make_ppm(task, material)
+    N_o, M = cloud.shape[0], task["eef_num"]
+    rec = Recorder(model)
+    np.random.seed(0)
+    t0 = time.time()
+    out = quiet(dynamics, torch.from_numpy(cloud), torch.from_numpy(action), model, torch.device("cpu"), ppm)
+    dt = time.time() - t0
+    B = action.shape[0]
+    mask = torch.ones((B, N_o + M), dtype=torch.bool)
+    tool = torch.zeros((B, N_o + M), dtype=torch.bool)
+    tool[:, N_o:] = True
+    for st in rec.steps:
+        assert_no_topk_boundary_tie(torch.from_numpy(st["state_last"]), mask, tool, task["adj_thresh"], task["topk"])
+    store = {"w::" + k: v for k, v in W.items()}
+    store["state0"], store["action"] = cloud, action
+    store["cand_ids"] = np.asarray(cand_ids, np.int32)
+    store["state_seqs"] = out["state_seqs"].numpy()
+    store["action_seqs"] = out["action_seqs"].numpy()
+    store["pstep"] = np.int32(dyn["model_config"]["pstep"])
+    store["task_json"] = np.frombuffer(json.dumps(task_scalars(task)).encode(), dtype=np.uint8)
+    F = len(rec.steps)
+    store["n_steps"] = np.int32(F)
+    store["pred_pos"] = np.stack([st["pred_pos"] for st in rec.steps])                       # (F, B, N_o, 3)
+    store["tool_pos"] = np.stack([st["state_last"][:, N_o:] for st in rec.steps])            # (F, B, M, 3)
+    cnt = np.zeros((F, B), np.int32)
+    sha = np.zeros((F, B, 32), np.uint8)
+    pairs = []
+    for f, st in enumerate(rec.steps):
+        for b, (r, s) in enumerate(st["edges"]):
+            cnt[f, b] = len(r)
+            sha[f, b] = np.frombuffer(hashlib.sha256(r.astype(np.int32).tobytes() + s.astype(np.int32).tobytes()).digest(), np.uint8)
+            pairs.append(np.stack([r, s], 1).astype(np.int16))
+    store["n_edges"], store["edges_sha256"] = cnt, sha
+    store["edges_i16"] = np.concatenate(pairs)                                              # (sum E, 2), (forward, candidate)-major
+    store["reference_seconds"] = np.float64(dt)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **store)
+    size = os.path.getsize(path) / 1e6
+    assert size < 4.0, size
+    print(f"{name}: {B} candidates x {F} forwards, E {cnt.min()}..{cnt.max()}, reference {dt:.1f} s "
+          f"({B * F / dt:.2f} rollout-steps/s, {torch.get_num_threads()} threads) -> {size:.2f} MB")
+
+
+def gen_fullsize_all():
+    refs = import_reference()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import bench as BN                                     # the benchmark's own input recipe (repo code, not the reference)
+    W = BN.random_weights(0)
+    # cloth: bench.py's inputs bit for bit (same generator sequence)
+    rng = np.random.default_rng(0)
+    cloud = BN.cloth_cloud(45, rng)
+    actions = BN.make_actions(1024, 2, 10, cloud, rng)
+    max_nR = int(1.2 * 6 * (cloud.shape[0] + 1)) + 64
+    assert BN.make_task(max_nR)["pusher_points"] == load_cfg("cloth")[1]["pusher_points"]
+    for name, ids in (("full_cloth_a", [0, 1023]), ("full_cloth_flip", [49, 487])):
+        gen_fullsize(name, "cloth", cloud, actions[ids], W, {"max_nR": max_nR}, refs, ids)
+    # granular: tools/bench_configs.py's inputs (cloud_of / make_actions with default_rng(0)), candidate 0
+    rng = np.random.default_rng(0)
+    g = (np.arange(32) - 31 / 2.0) * 0.12
+    xx, zz = np.meshgrid(g, g, indexing="ij")
+    p = np.stack([xx.ravel() - 2.0, np.zeros(1024), zz.ravel() + 1.0], 1)
+    gcloud = (p + rng.normal(0, 0.02, p.shape)).astype(np.float32)
+    gact = BN.make_actions(256, 2, 10, gcloud, rng)
+    gen_fullsize("full_granular", "granular", gcloud, gact[[0]], W, {"max_nR": int(1.2 * 25 * 1029) + 64}, refs, [0])
+
+
+if __name__ == "__main__" and "--fullsize" in sys.argv:
+    gen_fullsize_all()

@@ -63,3 +63,35 @@ def toy_planner_config(rollout, cost, action_dim=3, n_sample=16, n_update_iter=3
             "action_upper_lim": torch.tensor([0.5, 0.6, 1.0][:action_dim]),
             "planner_type": "MPPI", "device": "cpu", "verbose": False, "noise_type": noise_type, "noise_level": 0.2,
             "rollout_best": True}
+
+
+# ---- full-size fixtures recorded from the reference (tests/golden/make_golden.py --fullsize)
+def fullsize_records(g, task):
+    """-> per candidate: (records, capture, want).  records[f] = what the reference's forward f saw and produced
+    ('recv', 'send' int32, 'state_last' (N,3) = the positions its edge builder was fed, 'pred_pos' (N_o,3)); capture =
+    indices of the forwards whose prediction is captured into state_seqs; want = the state_seqs rows of the candidate."""
+    import hashlib
+    F, B = int(g["n_steps"]), g["action"].shape[0]
+    cnt, e16, sha = g["n_edges"], g["edges_i16"], g["edges_sha256"]
+    off = np.concatenate([[0], np.cumsum(cnt.ravel())])
+    rep = g["action"][..., 3].astype(np.int32)                       # plan_utils.py:16 (truncation)
+    assert (rep == rep[0]).all(), "the fixture's candidates share their repeats (forward f is the same step for all)"
+    H = rep.shape[1]
+    starts = np.concatenate([[0], np.cumsum(rep[0])])                # first forward of every look-ahead step
+    out = []
+    for b in range(B):
+        recs = []
+        for f in range(F):
+            k = f * B + b
+            pr = e16[off[k]:off[k + 1]].astype(np.int32)
+            r, s = np.ascontiguousarray(pr[:, 0]), np.ascontiguousarray(pr[:, 1])
+            assert hashlib.sha256(r.tobytes() + s.tobytes()).digest() == sha[f, b].tobytes(), (f, b)
+            li = int(np.searchsorted(starts, f, side="right") - 1)
+            if f == starts[li]:
+                obj = g["state0"] if li == 0 else g["state_seqs"][b, li - 1]
+            else:
+                obj = g["pred_pos"][f - 1, b]
+            recs.append({"recv": r, "send": s, "pred_pos": g["pred_pos"][f, b],
+                         "state_last": np.concatenate([obj, g["tool_pos"][f, b]], 0).astype(np.float32)})
+        out.append((recs, (starts[1:] - 1).tolist(), [g["state_seqs"][b, li] for li in range(H)]))
+    return out
