@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libadaptigraph_hip.so")
+# ADAPTIGRAPH_AMD_LIB: load another build of the same C-ABI instead (the diagnostic build libadaptigraph_hip_diag.so, for
+# tools/ and the injected-failure test).  The product never sets it.
+LIB_PATH = os.environ.get("ADAPTIGRAPH_AMD_LIB") or os.path.join(_HERE, "csrc", "libadaptigraph_hip.so")
 
 AG_OK = 0
 AG_ERR_INVALID = -1
@@ -26,7 +28,11 @@ EXPORTS = ["ag_abi_version", "ag_ctx_create", "ag_ctx_destroy", "ag_last_error",
            "ag_ctx_set_chunk", "ag_build_edges", "ag_forward", "ag_rollout", "ag_rollout_async",
            "ag_ctx_set_profiling", "ag_ctx_kernel_stats", "ag_ctx_reset_stats",
            "ag_cost_chamfer", "ag_cost_state_stats", "ag_cost_penalty", "ag_ctx_set_precision", "ag_build_edges_single",
-           "ag_edges_apply_tool_rule", "ag_mppi_sample", "ag_mppi_update", "ag_mppi_clip"]
+           "ag_edges_apply_tool_rule", "ag_mppi_sample", "ag_mppi_update", "ag_mppi_clip",
+           "ag_ctx_set_option", "ag_ctx_get_option", "ag_ctx_rollout_counts"]
+
+OPTIONS = ["streams", "chunk", "latency", "ragged", "ell_graph", "self_dedupe", "repeat_sort", "edge_wgs", "edge_block_min",
+           "enc_persist", "stagger_us", "device_decode"]
 
 
 class AgDims(C.Structure):
@@ -64,6 +70,9 @@ def load():
     lib.ag_ctx_load_weights.argtypes = [vp, C.POINTER(vp), i32]
     lib.ag_ctx_set_chunk.argtypes = [vp, i32]
     lib.ag_ctx_set_precision.argtypes = [vp, i32]
+    lib.ag_ctx_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.ag_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i32)]
+    lib.ag_ctx_rollout_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.ag_build_edges.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp, i32, i32, i32, vp, vp, vp, vp]
     lib.ag_build_edges_single.argtypes = [vp, vp, vp, vp, vp, i32, f32, f32, i32, i32, i32, vp, vp, vp, vp]
     lib.ag_edges_apply_tool_rule.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]

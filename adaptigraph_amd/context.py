@@ -94,6 +94,37 @@ class Engine:
         self.check(self.lib.ag_ctx_set_precision(self._ctx, {"fp32": 0, "bf16x3": 1}[mode]))
         self.precision = mode
 
+    def set_option(self, name, value):
+        """Per-context switch between bit-identical execution paths (include/adaptigraph_amd.h: ag_ctx_set_option)."""
+        self.check(self.lib.ag_ctx_set_option(self._ctx, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int32(0)
+        self.check(self.lib.ag_ctx_get_option(self._ctx, name.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """Context manager: set the given options, restore the previous values on exit."""
+        eng = self
+
+        class _Scope:
+            def __enter__(self):
+                self.old = {k: eng.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    eng.set_option(k, v)
+                return eng
+
+            def __exit__(self, *a):
+                for k, v in self.old.items():
+                    eng.set_option(k, v)
+        return _Scope()
+
+    def rollout_counts(self):
+        """(executed, needed) candidate-forwards of the last rollout call (ag_ctx_rollout_counts)."""
+        ex, need = C.c_int64(0), C.c_int64(0)
+        self.check(self.lib.ag_ctx_rollout_counts(self._ctx, C.byref(ex), C.byref(need)))
+        return ex.value, need.value
+
     def set_chunk(self, n):
         self.check(self.lib.ag_ctx_set_chunk(self._ctx, int(n)))
 

@@ -20,6 +20,11 @@ size_t lat_weights_offset(int which);
 hipError_t launch_edge_enc_lat(const float* wl, const GraphBufs& g, hipStream_t st);
 hipError_t launch_node_prop_lat(const float* wl, const GraphBufs& g, int round, bool last, float clamp, float* pred_pos,
                                 float* pred_motion, hipStream_t st);
+#ifdef AG_DIAG   // diagnostic build only (ag_diag.hip)
+void* diag_create();
+void diag_destroy(void* diag);
+int diag_fail_at_chunk(void* diag);
+#endif
 }
 using namespace ag;
 
@@ -54,8 +59,11 @@ struct ag_ctx {
     bool have_w = false;
     Slab slab;
     int chunk = 0;
-    int* d_repeat = nullptr; size_t repeat_cap = 0;
-    std::vector<int> h_repeat;   // ctx-owned copy so the caller's array may die right after the call
+    Options opt;                 // per-context switches: environment defaults read once at create, ag_ctx_set_option afterwards
+    void* diag = nullptr;        // diagnostic build only: probe state of this context (ag_diag.hip)
+    int* d_repeat = nullptr; size_t repeat_cap = 0;   // device: [repeat (B*H) | launch order (H*B)]
+    std::vector<int> h_repeat;   // ctx-owned copy so the caller's array may die right after the call; same layout
+    long long fwd_executed = 0, fwd_needed = 0;       // candidate-forwards of the last rollout call (ag_ctx_rollout_counts)
     int* d_overflow = nullptr;
     float* d_cself = nullptr;    // (256, NFP): rows 0/1 = C of an object / tool self-loop edge (see GraphBufs)
     // second in-library stream: alternate chunks run on it so that the HBM-bound kernels of one chunk overlap the
@@ -74,6 +82,21 @@ struct ag_ctx {
 };
 
 namespace {
+
+struct OptName { const char* name; const char* env; int Options::* field; bool env_negates; };
+const OptName kOptions[] = {
+    {"streams", "AG_STREAMS", &Options::streams, false},          {"chunk", "AG_CHUNK", &Options::chunk, false},
+    {"latency", "AG_LATENCY", &Options::latency, false},          {"ragged", "AG_NO_RAGGED", &Options::ragged, true},
+    {"ell_graph", "AG_NO_ELL_GRAPH", &Options::ell_graph, true},  {"self_dedupe", "AG_NO_SELF_DEDUPE", &Options::self_dedupe, true},
+    {"repeat_sort", "AG_NO_REPEAT_SORT", &Options::repeat_sort, true},
+    {"edge_wgs", "AG_EDGE_WGS", &Options::edge_wgs, false},       {"edge_block_min", "AG_EDGE_BLOCK_MIN", &Options::edge_block_min, false},
+    {"enc_persist", "AG_ENC_PERSIST", &Options::enc_persist, false}, {"stagger_us", "AG_STAGGER_US", &Options::stagger_us, false},
+    {"device_decode", "AG_DEVICE_DECODE", &Options::device_decode, false},
+};
+void options_from_env(Options& o) {
+    for (const OptName& n : kOptions)
+        if (const char* e = getenv(n.env)) o.*(n.field) = n.env_negates ? (atoi(e) ? 0 : 1) : atoi(e);
+}
 
 int fail(ag_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -291,6 +314,7 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
         for (int k = 0; k < 2; ++k) w.g.UV[par][k] = s.take<float>(rows * NFP);
     w.g.C = s.take<float>(((size_t)Bc * c_cap + 256) * NFP);   // + room for the two self-loop constant rows
     w.g.B = Bc; w.g.N = N; w.g.n_inst = n_inst; w.g.edge_cap = edge_cap; w.g.c_cap = c_cap; w.g.n_p = N_o;
+    w.g.enc_persist = c->opt.enc_persist; w.g.stagger_us = c->opt.stagger_us; w.g.diag = c->diag;
     if (own_edges) {
         w.ell = s.take<int>(rows * (size_t)std::max(1, ell_stride));
         w.deg = s.take<int>(rows);
@@ -324,11 +348,11 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
     return AG_OK;
 }
 
-int pick_slices(int B, int N) {
+int pick_slices(const ag_ctx* c, int B, int N) {
     // one sixteen-wave workgroup per CU: every workgroup re-reads its candidate's positions and re-derives the chunk
     // boxes, so fewer, longer row slices win (cloth, 128 candidates: 128 workgroups 56.8 ms per rollout, 256: 31.0,
     // 384: 43.1, 512: 35.2, 1024: 41.9)
-    static const int target = getenv("AG_EDGE_WGS") ? atoi(getenv("AG_EDGE_WGS")) : 256;
+    const int target = std::max(1, c->opt.edge_wgs);
     int s = (target + B - 1) / B;
     // a slice is at least 16 rows (one per wavefront of the workgroup): small batches are latency-bound, so a single
     // graph is spread over as many workgroups as that allows (one rope graph: 4 -> 18 workgroups, 43 -> 13 us per launch)
@@ -346,7 +370,7 @@ int clamp_chunk_for_offsets(int Bc, int N, int c_cap) {
 
 int auto_chunk(const ag_ctx* c, int B, int N) {
     if (c->chunk > 0) return std::min(c->chunk, B);
-    if (const char* e = getenv("AG_CHUNK")) { int v = atoi(e); if (v > 0) return std::min(v, B); }
+    if (c->opt.chunk > 0) return std::min(c->opt.chunk, B);
     // Node chains run 128-row workgroups, two per CU: the largest chunk whose workgroup count is <= 4 rounds of 512.
     // (Measured on the 1024 x 2026 cloth batch: 64 candidates/launch 574 ms, 96: 564, 128: 559, 192: 561, 256: 558 -
     // more rounds per launch dilute the lockstep store bursts and the launch tails; the workspace grows with it.)
@@ -361,8 +385,8 @@ int run_model(ag_ctx* c, const GraphBufs& g, float* pred_pos, float* pred_motion
     if (!g.cls_on) { Scoped p(c, FAM_NODE_ENC); HIPCHK(c, launch_node_enc(c->d_w, g, 0, (long)g.B * g.N, st)); }
     // Small launches are latency-bound: below one chip-filling round of 128-row workgroups the latency-mode chains take
     // over (ag_lat.hip: 32-row workgroups, every layer split over the four wavefronts; bit-identical results).
-    // AG_LATENCY: 0 never, 1 always, unset = by size.
-    const int lat_env = getenv("AG_LATENCY") ? atoi(getenv("AG_LATENCY")) : -1;   // read per call (tests toggle it)
+    // Options::latency: 0 never, 1 always, -1 = by size.
+    const int lat_env = c->opt.latency;
     const bool lat_ok = c->d_wlat && !g.wb3 && g.n_his != 5;
     const long edge_wgs = (long)g.B * g.c_cap / 128, node_wgs = ((long)g.B * g.N + 127) / 128;
     // (thresholds in 128-row workgroups of the throughput kernels: a latency workgroup reads its weight fragments from L2
@@ -434,6 +458,7 @@ int ag_ctx_create(int32_t device_id, const ag_dims* dims, ag_ctx** out) {
     *out = nullptr;
     ag_ctx* c = new ag_ctx();
     c->device = device_id; c->dims = *dims;
+    options_from_env(c->opt);
     *out = c;   // returned even on failure so the caller can read ag_last_error, then destroy
     const bool his_ok = (dims->n_his == 4 || dims->n_his == N_HIS_MAX) && dims->rel_dim == 5 + 3 * dims->n_his;
     if (dims->nf != NF || !his_ok || dims->in_dim != IN_DIM)
@@ -443,12 +468,18 @@ int ag_ctx_create(int32_t device_id, const ag_dims* dims, ag_ctx** out) {
     HIPCHK(c, hipSetDevice(device_id));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_w), (size_t)WeightLayout::TOTAL * 4));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_overflow), 256));
+#ifdef AG_DIAG
+    c->diag = diag_create();
+#endif
     return AG_OK;
 }
 
 int ag_ctx_destroy(ag_ctx* c) {
     if (!c) return AG_OK;
     (void)hipSetDevice(c->device);
+#ifdef AG_DIAG
+    diag_destroy(c->diag);
+#endif
     for (auto& p : c->prof_live) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -479,6 +510,26 @@ int ag_ctx_set_precision(ag_ctx* c, int32_t mode) {
 int ag_ctx_set_chunk(ag_ctx* c, int32_t n) {
     if (!c || n < 0) return AG_ERR_INVALID;
     c->chunk = n;
+    return AG_OK;
+}
+
+int ag_ctx_set_option(ag_ctx* c, const char* name, int32_t value) {
+    if (!c || !name) return AG_ERR_INVALID;
+    for (const OptName& n : kOptions)
+        if (!strcmp(name, n.name)) { c->opt.*(n.field) = value; return AG_OK; }
+    return fail(c, AG_ERR_INVALID, "unknown option '%s'", name);
+}
+
+int ag_ctx_get_option(ag_ctx* c, const char* name, int32_t* out) {
+    if (!c || !name || !out) return AG_ERR_INVALID;
+    for (const OptName& n : kOptions)
+        if (!strcmp(name, n.name)) { *out = c->opt.*(n.field); return AG_OK; }
+    return fail(c, AG_ERR_INVALID, "unknown option '%s'", name);
+}
+
+int ag_ctx_rollout_counts(ag_ctx* c, int64_t* out_executed, int64_t* out_needed) {
+    if (!c || !out_executed || !out_needed) return AG_ERR_INVALID;
+    *out_executed = c->fwd_executed; *out_needed = c->fwd_needed;
     return AG_OK;
 }
 
@@ -560,7 +611,7 @@ int ag_build_edges(ag_ctx* c, void* stream, const float* d_pos, const uint8_t* d
     int rc = check_topk(c, N, topk);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    const int slices = pick_slices(B, N);
+    const int slices = pick_slices(c, B, N);
     const size_t rows = (size_t)B * N;
     const int ell_stride = edge_ell_stride(N, topk);
     rc = ensure_slab(c, rows * (size_t)(ell_stride + 1) * 4 + (size_t)B * (slices + 1) * 4 + 4096);
@@ -573,7 +624,7 @@ int ag_build_edges(ag_ctx* c, void* stream, const float* d_pos, const uint8_t* d
     a.slice_tot = c->slab.take<int>((size_t)B * slices);
     a.cta_flag = c->slab.take<int>(B);
     a.recv = d_recv; a.send = d_send; a.row_ptr = d_row_ptr; a.n_edges = d_n_edges; a.overflow = nullptr;
-    a.max_nR = edge_cap; a.zero_on_overflow = 0;
+    a.max_nR = edge_cap; a.zero_on_overflow = 0; a.block_min_rows = c->opt.edge_block_min;
     c->prof_stream = static_cast<hipStream_t>(stream);
     HIPCHK(c, launch_edge_build(a, static_cast<hipStream_t>(stream), prof_mark, c));
     return AG_OK;
@@ -589,7 +640,7 @@ int ag_build_edges_single(ag_ctx* c, void* stream, const float* d_pos, const uin
     int rc = check_topk(c, N, topk);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    const int slices = pick_slices(1, N);
+    const int slices = pick_slices(c, 1, N);
     const int ell_stride = edge_ell_stride(N, topk);
     rc = ensure_slab(c, (size_t)N * (size_t)(ell_stride + 1) * 4 + (size_t)(slices + 1) * 4 + 4096);
     if (rc) return rc;
@@ -602,7 +653,7 @@ int ag_build_edges_single(ag_ctx* c, void* stream, const float* d_pos, const uin
     a.slice_tot = c->slab.take<int>(slices);
     a.cta_flag = c->slab.take<int>(1);
     a.recv = d_recv; a.send = d_send; a.row_ptr = d_row_ptr; a.n_edges = d_n_edges; a.overflow = nullptr;
-    a.max_nR = edge_cap; a.zero_on_overflow = 0;
+    a.max_nR = edge_cap; a.zero_on_overflow = 0; a.block_min_rows = c->opt.edge_block_min;
     c->prof_stream = static_cast<hipStream_t>(stream);
     HIPCHK(c, launch_edge_build(a, static_cast<hipStream_t>(stream), prof_mark, c));
     return AG_OK;
@@ -706,15 +757,6 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     c->prof_stream = st;
 
     const size_t nrep = (size_t)p->B * p->H;
-    if (c->repeat_cap < nrep) {
-        if (c->d_repeat) HIPCHK(c, hipFree(c->d_repeat));
-        c->d_repeat = nullptr; c->repeat_cap = 0;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_repeat), nrep * 4));
-        c->repeat_cap = nrep;
-    }
-    c->h_repeat.assign(h_repeat, h_repeat + nrep);
-    h_repeat = c->h_repeat.data();
-    HIPCHK(c, hipMemcpyAsync(c->d_repeat, h_repeat, nrep * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(d_state_seqs, 0, (size_t)p->B * p->H * p->N_o * 3 * 4, st));   // forward_dynamics.py:32
 
     const int k = std::min(N, p->topk);
@@ -722,9 +764,8 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     // Fast path (top-k active; the rollout keeps its tool particles behind the object particles): the count kernel's
     // per-row sender lists are used as the graph, slot-indexed (EdgeArgs::ell_full) - no emit pass, no CSR copy.
     // Every row then owns topk + M slots whatever max_nR is (the max_nR rule is applied by k_ell_index).
-    static const bool ell_env = !(getenv("AG_NO_ELL_GRAPH") && atoi(getenv("AG_NO_ELL_GRAPH")));
-    static const bool dedupe_env = !(getenv("AG_NO_SELF_DEDUPE") && atoi(getenv("AG_NO_SELF_DEDUPE")));
-    const bool ell_full = ell_env && dedupe_env && k < N;
+    const bool dedupe = c->opt.self_dedupe != 0;
+    const bool ell_full = c->opt.ell_graph && dedupe && k < N;
     const int edge_cap = (int)round_up((size_t)(ell_full ? bound : std::min<long>(bound, p->max_nR)), 256);
     int ns = std::max(1, std::min(c->n_streams, (int)ag_ctx::kMaxStreams));
     {   // batches of eight or more full-size chunks run on four streams (two chunks each): the memory-bound phases of
@@ -735,11 +776,17 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     }
     if ((long)p->B * N < 65536) ns = 1;   // small batches are dispatch-bound: a second stream only doubles the launches
                                           // (rope 64 x 301: 10.8 ms on one stream, 12.9 ms on two)
-    if (const char* e = getenv("AG_STREAMS")) ns = std::max(1, std::min(atoi(e), (int)ag_ctx::kMaxStreams));
+    if (c->opt.streams > 0) ns = std::min(c->opt.streams, (int)ag_ctx::kMaxStreams);
     // per-kernel event times are only meaningful without cross-stream interference; bit 30 of the mask keeps the
     // streams (the durations then include whatever the other stream ran beside the kernel)
     if ((c->prof_mask & 0x3fffffffu) && !(c->prof_mask & (1u << 30))) ns = 1;
-    int Bc = clamp_chunk_for_offsets(auto_chunk(c, p->B, N), N, edge_cap);
+    // Ragged batches (the masked variant: every candidate has its own number of valid particles): the propagate chains
+    // walk a compact row list, and one extra candidate slot per workspace - the phantom candidate, see GraphBufs - stands
+    // for every masked-out particle.  Options::ragged = 0 keeps the dense rows (A/B measurements).
+    const bool ragged = c->opt.ragged && p->y_mode == 1 && d_obj_mask != nullptr;
+    // (the phantom candidate's rows must stay inside the 32-bit element offsets too)
+    int Bc = ragged ? std::max(1, clamp_chunk_for_offsets(auto_chunk(c, p->B, N) + 1, N, edge_cap) - 1)
+                    : clamp_chunk_for_offsets(auto_chunk(c, p->B, N), N, edge_cap);
     if (ns > 1) Bc = std::min(Bc, (p->B + ns - 1) / ns);      // at least one chunk per stream
     {   // equal-sized chunks, a multiple of the stream count of them (no short last chunk, no idle stream at the end)
         int n_chunks = (p->B + Bc - 1) / Bc;
@@ -747,14 +794,41 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         Bc = (p->B + n_chunks - 1) / n_chunks;
     }
     if (p->B <= 1) ns = 1;
-    const int slices = pick_slices(Bc, N);
+    const int slices = pick_slices(c, Bc, N);
     const int ell = edge_ell_stride(N, p->topk);
-    // Ragged batches (the masked variant: every candidate has its own number of valid particles): the propagate chains
-    // walk a compact row list, and one extra candidate slot per workspace - the phantom candidate, see GraphBufs - stands
-    // for every masked-out particle.  AG_NO_RAGGED=1 keeps the dense rows (A/B measurements).
-    const bool ragged_env = !(getenv("AG_NO_RAGGED") && atoi(getenv("AG_NO_RAGGED")));      // read per call (tests toggle it)
-    const bool ragged = ragged_env && p->y_mode == 1 && d_obj_mask != nullptr;
     const int Ba = Bc + (ragged ? 1 : 0);                    // candidate slots per workspace
+
+    // Repeat-aware launch order (Options::repeat_sort).  The reference steps the WHOLE batch to the batch maximum of
+    // action_repeat and discards the surplus forwards (forward_dynamics.py:156-161).  Here, per launch chunk and
+    // look-ahead step, the chunk's candidates are put in descending order of their repeat count (stable): the candidates
+    // that still have forwards to run at step ai are then a PREFIX of the chunk's slots, and every kernel of that step is
+    // launched over that prefix only.  Executed candidate-forwards = sum of action_repeat, exactly.  A slot's candidate
+    // may change between look-ahead steps: the state carried from one to the next lives in d_state_seqs, which k_roll_init
+    // reads by candidate id.  Candidates are independent, so every candidate's result is bit-identical to the unsorted
+    // order's.  Ragged batches keep their slot order (their row list is built once per call).
+    const bool sort_on = c->opt.repeat_sort && !ragged;
+    if (c->repeat_cap < 2 * nrep) {
+        if (c->d_repeat) HIPCHK(c, hipFree(c->d_repeat));
+        c->d_repeat = nullptr; c->repeat_cap = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_repeat), 2 * nrep * 4));
+        c->repeat_cap = 2 * nrep;
+    }
+    c->h_repeat.resize(2 * nrep);
+    std::copy(h_repeat, h_repeat + nrep, c->h_repeat.begin());
+    h_repeat = c->h_repeat.data();
+    int* h_cand = c->h_repeat.data() + nrep;                 // [li][slot] -> candidate
+    for (int li = 0; li < p->H; ++li)
+        for (int b0 = 0; b0 < p->B; b0 += Bc) {
+            const int nb = std::min(Bc, p->B - b0);
+            int* seg = h_cand + (size_t)li * p->B + b0;
+            for (int b = 0; b < nb; ++b) seg[b] = b0 + b;
+            if (sort_on)
+                std::stable_sort(seg, seg + nb, [&](int x, int y) { return h_repeat[(size_t)x * p->H + li] > h_repeat[(size_t)y * p->H + li]; });
+        }
+    HIPCHK(c, hipMemcpyAsync(c->d_repeat, h_repeat, 2 * nrep * 4, hipMemcpyHostToDevice, st));
+    c->fwd_executed = 0; c->fwd_needed = 0;
+    for (size_t i = 0; i < nrep; ++i) c->fwd_needed += std::max(0, h_repeat[i]);
+
     const size_t wb = work_bytes(Ba, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
     rc = ensure_slab(c, wb * ns);
     if (rc) return rc;
@@ -777,8 +851,10 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         }
     }
 
-    // AG_TEST_FAIL_AT_CHUNK=n (test hook): fail with AG_ERR_HIP before enqueuing chunk n, as a failed launch would
-    const int fail_at = getenv("AG_TEST_FAIL_AT_CHUNK") ? atoi(getenv("AG_TEST_FAIL_AT_CHUNK")) : -1;
+    int fail_at = -1;
+#ifdef AG_DIAG   // AG_TEST_FAIL_AT_CHUNK=n (diagnostic build only): fail with AG_ERR_HIP before enqueuing chunk n, as a failed launch would
+    fail_at = diag_fail_at_chunk(c->diag);
+#endif
     // The chunk loop as a callable: whatever it returns, the forked streams are joined back into the caller's stream
     // below, so that a failure in the middle never leaves work of this call in flight on a stream the caller cannot see.
     auto enqueue_chunks = [&]() -> int {
@@ -793,7 +869,6 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         GraphBufs g = w.g;
         g.B = nb; g.n_p = p->N_o;
         g.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
-        static const bool dedupe = !(getenv("AG_NO_SELF_DEDUPE") && atoi(getenv("AG_NO_SELF_DEDUPE")));
         if (dedupe) {
             g.c_self = c->d_cself; g.ns_edge = w.ns_edge; g.n_ns = w.n_ns;
             g.self_row = (long)Ba * edge_cap;     // behind the last candidate's C rows of this workspace
@@ -810,7 +885,7 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         ea.B = nb; ea.N = N; ea.topk = p->topk; ea.cta = p->connect_tools_all ? 1 : 0; ea.edge_cap = edge_cap;
         ea.slices = slices; ea.ell = w.ell; ea.deg = w.deg; ea.slice_tot = w.slice_tot; ea.cta_flag = w.cta_flag;
         ea.recv = w.recv; ea.send = w.send; ea.row_ptr = w.row_ptr; ea.n_edges = w.n_edges;
-        ea.overflow = d_overflow_flag; ea.max_nR = p->max_nR; ea.zero_on_overflow = 1;
+        ea.overflow = d_overflow_flag; ea.max_nR = p->max_nR; ea.zero_on_overflow = 1; ea.block_min_rows = c->opt.edge_block_min;
         if (ell_full) {
             ea.ell_full = 1; ea.ell = w.send; ea.ell_stride = k + p->M; ea.ell_bstride = edge_cap;
             ea.ns_edge = w.ns_edge; ea.n_ns = w.n_ns;
@@ -823,9 +898,11 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
             g.rowlist = w.rowlist; g.n_rows = w.n_rows;
         }
         for (int li = 0; li < p->H; ++li) {
+            const int* seg = h_cand + (size_t)li * p->B + b0;    // slot -> candidate of this chunk and look-ahead step
             int max_rep = 0;
-            for (int b = 0; b < nb; ++b) max_rep = std::max(max_rep, h_repeat[(size_t)(b0 + b) * p->H + li]);
-            ra.li = li; ra.ai = 0;
+            for (int b = 0; b < nb; ++b) max_rep = std::max(max_rep, h_repeat[(size_t)seg[b] * p->H + li]);
+            ra.li = li; ra.ai = 0; ra.B = nb;
+            ra.cand = sort_on ? c->d_repeat + nrep + (size_t)li * p->B + b0 : nullptr;
             // masked variant: the object rows depend on nothing per-candidate either (both validity variants are
             // tabulated), so they are encoded once per call and workspace; tool rows once per look-ahead step
             ra.write_obj_cls = obj_cls_ready[ci % ns] ? 0 : 1;
@@ -835,9 +912,13 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
               if (!obj_cls_ready[ci % ns]) HIPCHK(c, launch_node_enc(c->d_w, g, 0, tool0 + (long)nb * p->M, cs));
               else HIPCHK(c, launch_node_enc(c->d_w, g, tool0, (long)nb * p->M, cs)); }
             obj_cls_ready[ci % ns] = true;
+            int n_live = nb;
             for (int ai = 1; ai <= max_rep; ++ai) {           // forward_dynamics.py:156
+                if (sort_on) while (n_live > 0 && h_repeat[(size_t)seg[n_live - 1] * p->H + li] < ai) --n_live;   // descending order: a prefix
+                ea.B = n_live; g.B = n_live; ra.B = n_live;
+                c->fwd_executed += n_live;
                 HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));
-                if (g.ns_edge && !ell_full) { Scoped s(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, nb, N, edge_cap, w.ns_edge, w.n_ns, cs)); }
+                if (g.ns_edge && !ell_full) { Scoped s(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, n_live, N, edge_cap, w.ns_edge, w.n_ns, cs)); }
                 rc = run_model(c, g, w.r.pred, w.r.motion, cs);
                 if (rc) return rc;
                 ra.ai = ai;

@@ -64,6 +64,23 @@ struct WeightLayout {
 enum Family { FAM_EDGE_COUNT = 0, FAM_EDGE_EMIT, FAM_PREP, FAM_NODE_ENC, FAM_EDGE_ENC, FAM_MP, FAM_NODE_PROP,
               FAM_NODE_FINAL, FAM_ROLL_INIT, FAM_ROLL_UPDATE, FAM_COST, FAM_COUNT };
 
+// ---- per-context tuning / A-B switches.  Defaults come from the environment ONCE, at ag_ctx_create (the AG_* name in
+// brackets); ag_ctx_set_option changes them per context afterwards.  None of them changes a result (bit-identical paths).
+struct Options {
+    int streams = 0;          // [AG_STREAMS]        in-library streams of a rollout: 0 = by batch size, else 1..4
+    int chunk = 0;            // [AG_CHUNK]          candidates per launch chunk: 0 = automatic (ag_ctx_set_chunk overrides)
+    int latency = -1;         // [AG_LATENCY]        latency-mode chains: -1 by size, 0 never, 1 always
+    int ragged = 1;           // [AG_NO_RAGGED]      masked rollouts walk a compact row list
+    int ell_graph = 1;        // [AG_NO_ELL_GRAPH]   rollout graphs stay slot-indexed (no CSR emit pass)
+    int self_dedupe = 1;      // [AG_NO_SELF_DEDUPE] self-loop edges skip the relation encoder
+    int repeat_sort = 1;      // [AG_NO_REPEAT_SORT] candidates of a chunk ordered by action_repeat, finished ones dropped
+    int edge_wgs = 256;       // [AG_EDGE_WGS]       edge-builder workgroups aimed at per launch
+    int edge_block_min = -1;  // [AG_EDGE_BLOCK_MIN] rows per slice from which the 64-rows-per-wavefront schedule is used (-1: built-in)
+    int enc_persist = 0;      // [AG_ENC_PERSIST]    persistent workgroups of k_edge_enc (0 = one per tile)
+    int stagger_us = 0;       // [AG_STAGGER_US]     offset between the two workgroups of a CU in the propagate chains
+    int device_decode = 0;    // [AG_DEVICE_DECODE]  read by the Python shim only (kept here so both sides list the same names)
+};
+
 // ---- launchers (defined in the .hip files) ------------------------------------------------------------
 struct EdgeArgs {
     const float* pos;           // (B,N,3) with `pos_bstride` floats between candidates
@@ -91,6 +108,7 @@ struct EdgeArgs {
     // the non-self-loop slot list (ns_edge, n_ns), n_edges, and applies the max_nR rule.
     int ell_full; int ell_stride; long ell_bstride;   // 0 / unset: ell_stride = min(topk,N), ell_bstride = N*ell_stride
     int* ns_edge; int* n_ns;
+    int block_min_rows;         // Options::edge_block_min (-1: built-in threshold)
 };
 hipError_t launch_edge_build(const EdgeArgs& a, hipStream_t st, void (*mark)(void*, int, int), void* mark_ctx);
 // list of non-self-loop edges per candidate (self-loop dedupe, see GraphBufs)
@@ -149,6 +167,8 @@ struct GraphBufs {
     // edges) appended to the list; k_roll_update applies it to the masked-out rows of every real candidate.
     const int* rowlist; const int* n_rows; // (B*N + N_o,), (1,) device; null = all rows
     int n_his;                             // 4 (0 = 4), or 5 on the forward path (feature rows then have pitch F15_PITCH)
+    int enc_persist, stagger_us;           // Options of the owning context
+    void* diag;                            // diagnostic build (-DAG_DIAG, ag_diag.hip) only: the context's probe state, else null
 };
 constexpr int B3_PHASE_BYTES = 2 * 5 * 3 * 64 * 16;   // 30,720
 constexpr int B3_PHASES = 58;
@@ -185,6 +205,8 @@ struct RollArgs {
     const uint8_t* obj_mask;                  // (Bfull,N_o) or null
     const float* eef_xz; const float* eef_delta;  // (Bfull,H,M,2), (Bfull,H,M,3)
     const int* repeat;                        // device (Bfull,H)
+    const int* cand;                          // null, or (B,) device: slot b of this chunk holds candidate cand[b] of the full
+                                              // batch (repeat-sorted launch order); null = candidate b0 + b
     float* state_seqs;                        // (Bfull,H,N_o,3)
 };
 // cost kernels (ag_cost.hip)

@@ -721,8 +721,7 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     a.ns_edge = h.ns_edge; a.n_ns = h.n_ns;
     a.recv = h.recv; a.send = h.send; a.row_ptr = h.row_ptr; a.n_edges = h.n_edges; a.overflow = h.overflow;
     a.max_nR = h.max_nR; a.zero_on_overflow = h.zero_on_overflow;
-    a.block_min_rows = BLOCK_MIN_ROWS;
-    if (const char* e = getenv("AG_EDGE_BLOCK_MIN")) a.block_min_rows = atoi(e);   // A/B switch; results identical
+    a.block_min_rows = h.block_min_rows >= 0 ? h.block_min_rows : BLOCK_MIN_ROWS;   // A/B switch (Options::edge_block_min); results identical
     const size_t lds = edge_lds_bytes(h.N);
     // the > 64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: track it per device ordinal
     static unsigned long long attr_devices = 0;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(RT) void k_roll_init(RollDev d) {
     __shared__ float red[RT];
     __shared__ int redi[RT];
     const RollArgs& a = d.a;
-    const int b = blockIdx.x, bg = a.b0 + b, tid = threadIdx.x;
+    const int b = blockIdx.x, bg = a.cand ? a.cand[b] : a.b0 + b, tid = threadIdx.x;
     const int N = a.N_o + a.M;
     const float* src = a.li == 0 ? (a.state0_batched ? a.state0 + (long)bg * a.N_o * 3 : a.state0)
                                  : a.state_seqs + ((long)bg * a.H + (a.li - 1)) * a.N_o * 3;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(RT) void k_roll_update(RollDev d) {
     __shared__ float red[RT];
     __shared__ int redi[RT];
     const RollArgs& a = d.a;
-    const int b = blockIdx.x, bg = a.b0 + b, tid = threadIdx.x;
+    const int b = blockIdx.x, bg = a.cand ? a.cand[b] : a.b0 + b, tid = threadIdx.x;
     const int N = a.N_o + a.M;
     float* pred = d.pred + (long)b * a.N_o * 3;
     const uint8_t* om = a.obj_mask ? a.obj_mask + (long)bg * a.N_o : nullptr;

@@ -345,8 +345,8 @@ __global__ __launch_bounds__(WGL, 2) void k_node_prop_lat(NDev g) {
             if (guard == 0) r.e0 = 0;
             r.deg = deg;
             const int* snd = g.send + (long)r.b * g.edge_cap + r.e0;
-            const int lastk = max(deg - 1, 0);
-            int idx0 = snd[min(c, lastk)], idx1 = snd[min(8 + c, lastk)];
+            const int lastk = max(deg - 1, 0), room = g.edge_cap - 1 - r.e0;  // (a degree-0 row at e0 == edge_cap reads the slot before)
+            int idx0 = snd[min(min(c, lastk), room)], idx1 = snd[min(min(8 + c, lastk), room)];
             if (c >= deg) idx0 = r.i;
             if (8 + c >= deg) idx1 = r.i;
             const int kmax = wave_max(deg);

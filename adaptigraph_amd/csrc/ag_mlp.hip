@@ -23,12 +23,14 @@
 //     row lands in: sharded == unsharded bit-for-bit.
 #include "ag_common.h"
 #include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <algorithm>
-#include <vector>
 
 namespace ag {
+#ifdef AG_DIAG   // in-kernel clock / phase probes of the diagnostic build (ag_diag.hip); the product library has none of it
+unsigned long long* diag_edge_begin(void* diag, unsigned nwg, hipStream_t st);
+void diag_edge_end(void* diag, unsigned nwg, hipStream_t st);
+unsigned long long* diag_node_begin(void* diag, unsigned nwg, hipStream_t st);
+void diag_node_end(void* diag, unsigned nwg, int round, hipStream_t st);
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -284,7 +286,9 @@ struct GDev {
     // all B*N rows; rowlist[slot] = dense row b*N + i, *n_rows = number of slots.  Null: every dense row, in order.
     const int* rowlist; const int* n_rows;
     int f_pitch, cur_off;                     // feature-row pitch and offset of the current position in it (n_his 4: 12, 9)
-    unsigned long long* dbg;   // diagnostic build of the clock probe only: 4 stamps per workgroup, never read by kernels
+#ifdef AG_DIAG
+    unsigned long long* dbg;   // diagnostic build (ag_diag.hip) only: stamps per workgroup, never read by kernels
+#endif
 };
 
 using WL = WeightLayout;
@@ -445,7 +449,9 @@ __device__ __forceinline__ void gather_agg(const GDev& g, float* stg, long wave_
         // from here, first used at edge 8
         const int* snd = senders_of(r);
         const int lastk = max(r.deg - 1, 0);
-        int idx1 = snd[min(8 + c, lastk)], idx2 = snd[min(16 + c, lastk)], idx3 = snd[min(24 + c, lastk)];
+        // (offsets clamped to the candidate's slots like pidx0: a degree-0 row at e0 == edge_cap must not read past the array)
+        const int room = g.edge_cap - 1 - r.e0;
+        int idx1 = snd[min(min(8 + c, lastk), room)], idx2 = snd[min(min(16 + c, lastk), room)], idx3 = snd[min(min(24 + c, lastk), room)];
         if (8 + c >= r.deg) idx1 = r.i;
         if (16 + c >= r.deg) idx2 = r.i;
         if (24 + c >= r.deg) idx3 = r.i;
@@ -547,10 +553,12 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
     const int e0 = (int)(blk / (unsigned)g.B) * WG_ROWS;
     const int ne = g.n_ns ? g.n_ns[b] : g.n_edges[b];       // rows to encode: all edges, or the non-self-loop ones
     if (e0 >= ne) continue;                                  // whole workgroup past this candidate's edges
+#ifdef AG_DIAG
     if (g.dbg && tid == 0) {
         g.dbg[blk * 4 + 0] = __builtin_amdgcn_s_memtime();
         g.dbg[blk * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
 
     // small first-layer panel -> buffer 1; under its MFMAs, L2 half 0 -> buffer 0
     stage_now<EDGE_L1_CHUNKS * CHUNK_FLOATS_MB5>(lds + BUF_FLOATS, wts + WL::E_L1, tid);
@@ -592,10 +600,12 @@ __global__ __launch_bounds__(WG, 2) void k_edge_enc(GDev g) {
     relu_one(y, lane);
     layer160<0>(lds, wts + WL::E_W1, nullptr, y, x, tid, lane);
     store_rows_t(x, g.C, (int)((long)b * g.c_cap + el), valid, stg, lane);
+#ifdef AG_DIAG
     if (g.dbg && tid == 0) {
         g.dbg[blk * 4 + 2] = __builtin_amdgcn_s_memtime();
         g.dbg[blk * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
     __syncthreads();                                         // the weight buffers are restaged by the next tile
     }
 }
@@ -655,6 +665,7 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     const long row = rowc;
 
     stagger_second_workgroup(g);
+#ifdef AG_DIAG
     if (g.dbg && tid == 0) {
         g.dbg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));        // HW_REG_HW_ID: cu [11:8], se [15:13]
@@ -662,13 +673,16 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
         g.dbg[(unsigned long)gridDim.x * 4 + blockIdx.x] = (xcc << 8) | (((hw >> 13) & 7) << 4) | ((hw >> 8) & 15);
         g.dbg[(unsigned long)gridDim.x * 5 + 2 * blockIdx.x] = __builtin_amdgcn_s_memtime();
     }
+#endif
     dma_copy<Q_FLOATS>(lds, g.w + WL::P_WB, tid);          // first quarter of Wb lands under the gather / row loads
     Act x, y;
     // The residual terms seed the accumulator: y = P + eff, then y += Wb*agg.  All three row loads are issued here,
     // together, instead of two of them stalling the chain after the Wb layer.
     gather_agg(g, stg, (long)blockIdx.x * WG_ROWS + wave * 32, nrows, x, lane);
     __builtin_amdgcn_sched_barrier(0);                       // nothing of what follows is worth a register during the gather
+#ifdef AG_DIAG
     if (g.dbg && tid == 0) g.dbg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int pb = (int)(rowc / g.N), pi = (int)(rowc - (long)pb * g.N);
     const long crow = g.cls_on ? cls_row(g, pb, pi) : rowc;
     const bool ceff = g.cls_on && g.first_round;             // round 1: the previous effect is p_enc itself
@@ -680,7 +694,9 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     __syncthreads();                                         // Wb quarter 0 is in buffer 0
     layer160<Q_FLOATS, false>(lds, g.w + WL::P_WB, g.w + (LAST ? WL::P_P0 : WL::N_W2), x, y, tid, lane);
     relu_one(y, lane);                                       // y = new particle effect (slot 150 forced to 1)
+#ifdef AG_DIAG
     if (g.dbg && tid == 0) g.dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (!LAST) {
         // quarter 1 of the next layer is requested BEFORE each burst of row stores, so that the wait for it at the next
         // barrier leaves the stores in flight: they then have two quarter sweeps to drain instead of one
@@ -691,10 +707,12 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
         store_rows_t(x, g.U, (int)row, valid, stg, lane);
         layer160<0, true, true>(lds, g.w + WL::N_W3, nullptr, y, x, tid, lane);
         store_rows_t(x, g.V, (int)row, valid, stg, lane);
+#ifdef AG_DIAG
         if (g.dbg && tid == 0) {
             g.dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
             g.dbg[(unsigned long)gridDim.x * 5 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
         }
+#endif
     } else {
         layer160<Q_FLOATS>(lds, g.w + WL::P_P0, g.w + WL::P_P1, y, x, tid, lane);
         relu_one(x, lane);
@@ -1048,12 +1066,13 @@ static GDev to_dev(const float* w, const GraphBufs& g) {
     d.self_row = (unsigned)g.self_row; d.n_guard = g.n_guard;
     d.rowlist = g.rowlist; d.n_rows = g.n_rows;
     d.f_pitch = feat_pitch(g.n_his); d.cur_off = g.n_his == 5 ? 12 : 9;
-    // AG_STAGGER_US: offset between the two workgroups of a CU in the fused propagate chains.  Off by default: it removes
+    // Options::stagger_us: offset between the two workgroups of a CU in the fused propagate chains.  Off by default: it removes
     // the "both computing / both gathering" states (probe: 8 % -> 0 % of CU time) but the kernel time moves by <= 1 %
     // either way (two streams: 169 vs 171 ms per rollout with 30 us; four streams: 484.9 vs 482.9 ms per rollout without)
-    static const int stagger_us = getenv("AG_STAGGER_US") ? atoi(getenv("AG_STAGGER_US")) : 0;
-    d.stagger_ticks = stagger_us * 100; d.first_wave = 512;
+    d.stagger_ticks = g.stagger_us * 100; d.first_wave = 512;
+#ifdef AG_DIAG
     d.dbg = nullptr;
+#endif
     return d;
 }
 // upper bound of the work-list length: every dense row, plus the phantom candidate's object rows of a ragged batch
@@ -1065,39 +1084,21 @@ hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
     const long rows = (long)g.B * g.c_cap;
     const unsigned nwg = (unsigned)(rows / WG_ROWS);
     GDev d = to_dev(w, g);
-    // AG_CLOCK_PROBE=n : diagnostic mode (synchronises!): stamp the first n launches and print the in-kernel clock
-    static int probe_left = getenv("AG_CLOCK_PROBE") ? atoi(getenv("AG_CLOCK_PROBE")) : 0;
-    static unsigned long long* dbg = nullptr;
-    static unsigned dbg_cap = 0;
-    if (probe_left > 0) {
-        if (dbg_cap < nwg) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, (size_t)nwg * 32); dbg_cap = nwg; }
-        (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 32, st);
-        d.dbg = dbg;
-    }
+    bool probing = false;
+#ifdef AG_DIAG
+    d.dbg = diag_edge_begin(g.diag, nwg, st);
+    probing = d.dbg != nullptr;
+#endif
     if (d.wb3) hipLaunchKernelGGL(k_edge_enc_b3, dim3((unsigned)(rows / WGB_ROWS)), dim3(WGB), 0, st, d);
     else if (g.n_his == 5) hipLaunchKernelGGL(k_edge_enc<5>, dim3(nwg), dim3(WG), 0, st, d);
     else {
-        const char* pe = getenv("AG_ENC_PERSIST");                             // read per call (tests toggle it)
-        const int persist = pe ? atoi(pe) : 0;
         unsigned grid = nwg;
-        if (persist > 0 && probe_left <= 0 && nwg > (unsigned)persist) { d.n_tiles = nwg; grid = (unsigned)persist; }
+        if (g.enc_persist > 0 && !probing && nwg > (unsigned)g.enc_persist) { d.n_tiles = nwg; grid = (unsigned)g.enc_persist; }
         hipLaunchKernelGGL(k_edge_enc<4>, dim3(grid), dim3(WG), 0, st, d);
     }
-    if (probe_left > 0) {
-        --probe_left;
-        (void)hipStreamSynchronize(st);
-        unsigned long long* h = (unsigned long long*)malloc((size_t)nwg * 32);
-        (void)hipMemcpy(h, dbg, (size_t)nwg * 32, hipMemcpyDeviceToHost);
-        double sum = 0, sumc = 0; int n = 0; double mn = 1e9, mx = 0;
-        for (unsigned i = 0; i < nwg; ++i) {
-            if (!h[4 * i + 3] || h[4 * i + 3] == h[4 * i + 1]) continue;
-            const double cyc = (double)(h[4 * i + 2] - h[4 * i + 0]), rt = (double)(h[4 * i + 3] - h[4 * i + 1]);
-            const double ghz = cyc / rt * 0.1;   // s_memrealtime ticks at 100 MHz
-            sum += ghz; sumc += cyc; ++n; mn = ghz < mn ? ghz : mn; mx = ghz > mx ? ghz : mx;
-        }
-        if (n) fprintf(stderr, "[ag clock probe] k_edge_enc: %d workgroups, in-kernel clock mean %.3f GHz (min %.3f max %.3f), mean WG lifetime %.0f cycles\n", n, sum / n, mn, mx, sumc / n);
-        free(h);
-    }
+#ifdef AG_DIAG
+    if (probing) diag_edge_end(g.diag, nwg, st);
+#endif
     return hipGetLastError();
 }
 hipError_t launch_node_enc(const float* w, const GraphBufs& g, long row0, long nrows, hipStream_t st) {
@@ -1125,89 +1126,15 @@ static void set_round(GDev& d, const GraphBufs& g, int round) {
 hipError_t launch_node_prop(const float* w, const GraphBufs& g, int round, hipStream_t st) {
     GDev d = to_dev(w, g);
     set_round(d, g, round);
-    // AG_NODE_PROBE=n : diagnostic mode (synchronises!): stamp the phases of the first n launches (s_memrealtime, 10 ns)
-    static int probe_left = getenv("AG_NODE_PROBE") ? atoi(getenv("AG_NODE_PROBE")) : 0;
-    static unsigned long long* dbg = nullptr;
-    static unsigned dbg_cap = 0;
     const unsigned nwg = (unsigned)node_grid(g);
-    // AG_NODE_PROBE=-1: stamp EVERY launch without synchronising (each overwrites the last) and report the in-kernel clock of
-    // the final launch at process exit: the clock the chip holds in the middle of a sustained run
-    static bool probe_tail = getenv("AG_NODE_PROBE") && atoi(getenv("AG_NODE_PROBE")) < 0;
-    if (probe_tail && !d.wb3) {
-        static unsigned tail_nwg = 0;
-        if (dbg_cap < nwg) {
-            if (dbg) (void)hipFree(dbg);
-            (void)hipMalloc((void**)&dbg, (size_t)nwg * 56); dbg_cap = nwg;
-            (void)hipMemset(dbg, 0, (size_t)nwg * 56);
-            static bool reg = false;
-            if (!reg) {
-                reg = true;
-                atexit([]() {
-                    (void)hipDeviceSynchronize();
-                    std::vector<unsigned long long> h((size_t)tail_nwg * 7);
-                    (void)hipMemcpy(h.data(), dbg, (size_t)tail_nwg * 56, hipMemcpyDeviceToHost);
-                    double ghz = 0; int n = 0;
-                    for (unsigned i = 0; i < tail_nwg; ++i) {
-                        const unsigned long long c0 = h[(size_t)tail_nwg * 5 + 2 * i], c1 = h[(size_t)tail_nwg * 5 + 2 * i + 1];
-                        if (c1 > c0 && h[4 * i + 3] > h[4 * i]) { ghz += (double)(c1 - c0) / (double)(h[4 * i + 3] - h[4 * i]) * 0.1; ++n; }
-                    }
-                    if (n) fprintf(stderr, "[ag node probe] last k_node_prop<false> launch of the process: in-kernel clock %.3f GHz over %d workgroups\n", ghz / n, n);
-                });
-            }
-        }
-        tail_nwg = nwg;
-        d.dbg = dbg;
-    }
-    if (probe_left > 0 && !d.wb3) {
-        if (dbg_cap < nwg) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, (size_t)nwg * 56); dbg_cap = nwg; }
-        (void)hipMemsetAsync(dbg, 0, (size_t)nwg * 56, st);
-        d.dbg = dbg;
-    }
+#ifdef AG_DIAG
+    if (!d.wb3) d.dbg = diag_node_begin(g.diag, nwg, st);
+#endif
     if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<false>, dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
     else hipLaunchKernelGGL(k_node_prop<false>, dim3(nwg), dim3(WG), 0, st, d);
-    if (d.dbg && !probe_tail) {
-        --probe_left;
-        (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h((size_t)nwg * 7);
-        (void)hipMemcpy(h.data(), dbg, (size_t)nwg * 56, hipMemcpyDeviceToHost);
-        double ghz = 0; int nghz = 0;
-        for (unsigned i = 0; i < nwg; ++i) {
-            const unsigned long long c0 = h[(size_t)nwg * 5 + 2 * i], c1 = h[(size_t)nwg * 5 + 2 * i + 1];
-            if (c1 > c0 && h[4 * i + 3] > h[4 * i]) { ghz += (double)(c1 - c0) / (double)(h[4 * i + 3] - h[4 * i]) * 0.1; ++nghz; }
-        }
-        unsigned long long t0 = ~0ull, t1 = 0;
-        double a = 0, b = 0, c2 = 0; int n = 0;
-        for (unsigned i = 0; i < nwg; ++i) {
-            if (!h[4 * i + 3]) continue;
-            t0 = std::min(t0, h[4 * i]); t1 = std::max(t1, h[4 * i + 3]);
-            a += (double)(h[4 * i + 1] - h[4 * i]); b += (double)(h[4 * i + 2] - h[4 * i + 1]); c2 += (double)(h[4 * i + 3] - h[4 * i + 2]); ++n;
-        }
-        // per CU: how much of the launch had 0 / 1 / 2 workgroups in their chain phase (stamps 1..3), and in their gather
-        std::vector<std::vector<unsigned>> by_cu(2048);
-        for (unsigned i = 0; i < nwg; ++i) if (h[4 * i + 3]) by_cu[h[(size_t)nwg * 4 + i] & 0x7ff].push_back(i);
-        double chain[3] = {0, 0, 0}, gath[3] = {0, 0, 0}; int ncu = 0;
-        for (auto& v : by_cu) {
-            if (v.empty()) continue;
-            ++ncu;
-            std::vector<std::pair<unsigned long long, int>> ev, eg;
-            for (unsigned i : v) {
-                ev.push_back({h[4 * i + 1], +1}); ev.push_back({h[4 * i + 3], -1});
-                eg.push_back({h[4 * i + 0], +1}); eg.push_back({h[4 * i + 1], -1});
-            }
-            auto sweep = [&](std::vector<std::pair<unsigned long long, int>>& e, double* acc) {
-                std::sort(e.begin(), e.end());
-                int lvl = 0; unsigned long long prev = t0;
-                for (auto& x : e) { acc[std::min(lvl, 2)] += (double)(x.first - prev); prev = x.first; lvl += x.second; }
-                acc[0] += (double)(t1 - prev);
-            };
-            sweep(ev, chain); sweep(eg, gath);
-        }
-        const double span = (double)(t1 - t0) * ncu;
-        if (n) fprintf(stderr, "[ag node probe] round %d: %d workgroups on %d CUs, span %.1f us; mean per workgroup: gather+loads %.1f us, Wb layer %.1f us, "
-                               "W2+W3 layers+stores %.1f us, in-kernel clock %.3f GHz | CU time with 0/1/2 workgroups in chain: %.0f%% %.0f%% %.0f%%; in gather: %.0f%% %.0f%% %.0f%%\n",
-                       round, n, ncu, (t1 - t0) * 0.01, a / n * 0.01, b / n * 0.01, c2 / n * 0.01, nghz ? ghz / nghz : 0.0,
-                       100 * chain[0] / span, 100 * chain[1] / span, 100 * chain[2] / span, 100 * gath[0] / span, 100 * gath[1] / span, 100 * gath[2] / span);
-    }
+#ifdef AG_DIAG
+    if (d.dbg) diag_node_end(g.diag, nwg, round, st);
+#endif
     return hipGetLastError();
 }
 hipError_t launch_node_final(const float* w, const GraphBufs& g, int round, float clamp, float* pred_pos,

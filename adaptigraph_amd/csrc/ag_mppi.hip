@@ -24,11 +24,14 @@ __device__ __forceinline__ float floor_mod(float x, float d) {
     if (r != 0.0f && r < 0.0f) r += d;
     return r;
 }
-// (theta, length) of the push start -> end, then the limits: plan_utils.py:31-39 (clip_actions)
+// (theta, length) of the push start -> end, then the limits: plan_utils.py:31-39 (clip_actions).  A NaN stays a NaN, as in
+// the reference (clamp_ propagates it): a NaN reward makes every softmax weight, hence the whole updated action, NaN - the
+// fmaxf of the max pass drops it, but exp(NaN - m) brings it back into the normaliser - and must not come out as a
+// valid-looking action at the lower limit.
 __device__ __forceinline__ void limit4(float v[4], const float* lo, const float* hi) {
     v[2] = floor_mod(v[2] + PI_F, TWO_PI_F) - PI_F;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = fminf(fmaxf(v[k], lo[k]), hi[k]);
+    for (int k = 0; k < 4; ++k) v[k] = v[k] != v[k] ? v[k] : fminf(fmaxf(v[k], lo[k]), hi[k]);   // torch.clamp propagates NaN
 }
 __device__ __forceinline__ void encode_limit(float xs, float ys, float xe, float ye, float pl, const float* lo,
                                              const float* hi, float* out) {

@@ -48,6 +48,29 @@ def farthest_points(points, num, init_idx=-1):
     return pts[chosen]
 
 
+def _require_rank_local(fn, what):
+    """Raise if `fn` is a functools.partial (possibly nested, possibly around other partials in its keywords) that binds a
+    non-None `group`: such a callable all-reduces inside every call."""
+    import functools
+    seen = []
+
+    def walk(f):
+        if isinstance(f, functools.partial):
+            for k, v in (f.keywords or {}).items():
+                if k == "group" and v is not None:
+                    seen.append(k)
+                walk(v)
+            for v in f.args:
+                walk(v)
+            walk(f.func)
+    walk(fn)
+    if seen:
+        raise ValueError(f"trajectory_optimization_chunked with a process group needs a rank-local {what}: it was built with "
+                         "group=... and would issue a collective per call, but the ranks evaluate different numbers of chunks "
+                         "(mismatched collectives hang). Build it with group=None; use mpc_iteration for one batch sharded "
+                         "over the ranks with batch-global maxima.")
+
+
 class Planner(object):
     _REQUIRED = ("action_dim", "model_rollout_fn", "evaluate_traj_fn", "n_sample", "n_look_ahead", "n_update_iter",
                  "reward_weight", "action_lower_lim", "action_upper_lim", "planner_type")
@@ -223,6 +246,14 @@ class Planner(object):
         import torch.distributed as dist
         from .sharding import shard_bounds, all_gather_costs
         sharded = self.group is not None and dist.is_available() and dist.is_initialized()
+        if sharded:
+            # chunks are dealt to the ranks, so the ranks call the evaluation a DIFFERENT number of times (zero for some when
+            # n_chunk < world): an evaluation that issues a collective per call (running_cost / cloth_penalty built with
+            # group=..., as mpc_iteration wants them) would leave the ranks in mismatched collectives - a hang.  Chunk
+            # maxima are chunk-local by the reference's own semantics (plan.py:37, losses.py:62 see one chunk), so the
+            # callables handed to this entry must be rank-local.
+            _require_rank_local(self.evaluate_traj, "evaluate_traj_fn")
+            _require_rank_local(self.model_rollout, "model_rollout_fn")
         pg = None if self.group in (None, True) else self.group
         world = dist.get_world_size(pg) if sharded else 1
         rank = dist.get_rank(pg) if sharded else 0

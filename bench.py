@@ -109,7 +109,8 @@ def cpu_baseline(cloud, task, W, actions, picks, gpu_seqs, tol=1e-5):
     tie_margin = 4.0 * float(task["adj_thresh"]) * tol
     tie_prone = np.minimum.accumulate(margin, axis=1) < tie_margin
     within = err <= tol
-    unexplained = ~within & ~tie_prone
+    post_flip_bound = 1e-3                                   # a flipped edge moves a particle by ~1e-4..1e-3 over the rest of the rollout
+    unexplained = ~within & (~tie_prone | (err > post_flip_bound))
     clean = within.all(1)
     flips = [{"candidate": int(picks[i]), "lookahead_step": int(h), "abs_err": float(err[i, h]),
               "oracle_selection_margin": float(np.minimum.accumulate(margin, axis=1)[i, h])}
@@ -119,11 +120,15 @@ def cpu_baseline(cloud, task, W, actions, picks, gpu_seqs, tol=1e-5):
                       f"(cloth 2025+1 particles), one candidate per process and BLAS thread, {dt:.1f}s wall"}
     parity = {"candidates": [int(p) for p in picks], "max_abs_err": float(err[within].max()) if within.any() else None,
               "tol": tol, "candidates_within_tol_all_steps": int(clean.sum()), "edge_flips": flips,
-              "ok": bool(not unexplained.any() and clean.sum() * 2 >= len(picks)),
+              "ok": bool(not unexplained.any() and clean.sum() * 10 >= 9 * len(picks)),
               "what": "state_seqs of these candidates from the LAST TIMED step vs the oracle, free-running over all "
                       "steps; max_abs_err is over the (candidate, look-ahead step) pairs within tol; edge_flips lists the "
                       "others, each of which must follow a near-tie in the oracle's own edge selection "
-                      f"(margin < {tie_margin:.1e} in squared distance) - otherwise ok is false"}
+                      f"(margin < {tie_margin:.1e} in squared distance) at or before that look-ahead step and stay below "
+                      f"{post_flip_bound:.0e} - otherwise ok is false; ok also needs >= 90 % of the candidates within tol at "
+                      "every step.  Context (tests/test_fullsize_golden.py, tests/test_gpu_fullsize_golden.py): on candidates "
+                      "49 and 487 of this batch the reference, the 8-thread oracle and the GPU agree to 2e-6 over all 20 steps; "
+                      "the single-thread oracle of this leg sums in another order and parts from all three at such a tie"}
     return base, parity
 
 

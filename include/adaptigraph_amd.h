@@ -40,7 +40,7 @@ extern "C" {
 #define AG_ERR_UNSUPPORTED -4  /* configuration outside what the kernels implement                            */
 #define AG_ERR_NO_WEIGHTS -5   /* forward/rollout before ag_ctx_load_weights                                   */
 
-#define AG_ABI_VERSION 4
+#define AG_ABI_VERSION 5
 #define AG_NUM_WEIGHT_TENSORS 22
 
 typedef struct ag_ctx ag_ctx;
@@ -101,6 +101,32 @@ int ag_ctx_set_precision(ag_ctx* ctx, int32_t mode);
 /* Tuning: candidates per launch wave of the rollout (0 = automatic). */
 int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
 
+/* Per-context switches between bit-identical execution paths (A/B measurements, tests).  A context takes its defaults
+ * from the environment ONCE, at ag_ctx_create (AG_* name in brackets); afterwards only these calls change them, so two
+ * contexts of one process can differ.  No call of the library reads the environment after ag_ctx_create.
+ *   "streams"        [AG_STREAMS]         in-library HIP streams of a rollout: 0 = by batch size (default), 1..4
+ *   "chunk"          [AG_CHUNK]           candidates per launch chunk, 0 = automatic (ag_ctx_set_chunk takes precedence)
+ *   "latency"        [AG_LATENCY]         latency-mode chains: -1 by launch size (default), 0 never, 1 always
+ *   "ragged"         [AG_NO_RAGGED=1 -> 0]      masked rollouts walk a compact row list (default 1)
+ *   "ell_graph"      [AG_NO_ELL_GRAPH=1 -> 0]   rollout graphs stay slot-indexed, no CSR emit pass (default 1)
+ *   "self_dedupe"    [AG_NO_SELF_DEDUPE=1 -> 0] self-loop edges skip the relation encoder (default 1)
+ *   "repeat_sort"    [AG_NO_REPEAT_SORT=1 -> 0] repeat-aware launch order of ag_rollout (default 1, see there)
+ *   "edge_wgs"       [AG_EDGE_WGS]        workgroups the edge builder aims at per launch (default 256)
+ *   "edge_block_min" [AG_EDGE_BLOCK_MIN]  rows per slice from which the 64-rows-per-wavefront schedule is used (-1 = built-in 256)
+ *   "enc_persist"    [AG_ENC_PERSIST]     persistent workgroups of k_edge_enc (default 0 = one workgroup per tile)
+ *   "stagger_us"     [AG_STAGGER_US]      start offset between the two workgroups of a CU in the propagate chains (default 0)
+ *   "device_decode"  [AG_DEVICE_DECODE]   consumed by the Python shim: decode_action / tool layout on the device (default 0)
+ * Unknown names return AG_ERR_INVALID. */
+int ag_ctx_set_option(ag_ctx* ctx, const char* name, int32_t value);
+int ag_ctx_get_option(ag_ctx* ctx, const char* name, int32_t* out_value);
+
+/* Candidate-forwards of the LAST ag_rollout / ag_rollout_async call on this context: executed (sum over launches of the
+ * candidates each model forward was launched over) and needed (sum of action_repeat over the batch).  With the
+ * repeat-aware launch order the two are equal; with "repeat_sort" 0 (and for masked batches) every candidate of a launch
+ * chunk is stepped to the chunk's maximum, as the reference steps the whole batch to the batch maximum
+ * (forward_dynamics.py:156-161). */
+int ag_ctx_rollout_counts(ag_ctx* ctx, int64_t* out_executed, int64_t* out_needed);
+
 /* Replaces construct_edges_from_states_batch (src/dynamics/dataset/graph.py:233-298).
  *   d_pos (B,N,3); d_mask,d_tool_mask (B,N) uint8; adj_thresh scalar, or d_adj_thresh_vec (B,) if non-NULL.
  * Outputs, per batch element b, in the reference's nonzero order (sorted by receiver, then sender):
@@ -158,7 +184,10 @@ int ag_forward(ag_ctx* ctx, void* stream, const float* d_state, const float* d_a
  *   d_obj_mask    (B,N_o) uint8 or NULL (= all valid)                                   (:107-115 / :302-309)
  *   d_eef_xz      (B,H,M,2) tool start x,z per look-ahead step; d_eef_delta (B,H,M,3)   (:42-75, computed by the shim
  *                 with torch CPU ops exactly as the reference does, so cos/sin bits match)
- *   h_repeat      (B,H) int32 HOST array = action_repeat (plan_utils.py:16)
+ *   h_repeat      (B,H) int32 HOST array = action_repeat (plan_utils.py:16).  A candidate is stepped exactly
+ *                 h_repeat[b,h] times in look-ahead step h: per launch chunk the candidates are put in descending order
+ *                 of their repeat count and every step is launched over the prefix that is still live (the reference steps
+ *                 all of them to the batch maximum and discards the surplus, forward_dynamics.py:156-161; same outputs)
  *   d_phys_vec    NULL (use p->physics_param for every object particle), or (N_o,) per-particle physics parameters
  *                 shared by all candidates (the (B,n_p) branch of model.py:200-204 fed by forward_dynamics.py:151)
  *   d_state_seqs  (B,H,N_o,3) output, fully written (zeros where repeat==0, :32)

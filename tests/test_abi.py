@@ -25,10 +25,30 @@ def test_library_exports_every_declared_symbol():
     assert declared == sorted(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ag_abi_version() == 4
+    assert lib.ag_abi_version() == 5
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = sorted(set(re.findall(r" T (ag_[a-z_]+)$", out, flags=re.M)))
     assert exported == declared, (exported, declared)
+
+
+def test_product_library_has_no_probe_or_environment_code():
+    """The clock / phase probes and the injected-failure hook live in the diagnostic build only (-DAG_DIAG); the product
+    library reads the environment in ONE place (the option defaults of ag_ctx_create) and registers no exit handler."""
+    from adaptigraph_amd import _lib
+    strings = subprocess.run(["strings", "-n", "6", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    for word in ("AG_CLOCK_PROBE", "AG_NODE_PROBE", "AG_TEST_FAIL_AT_CHUNK", "[ag clock probe]", "[ag node probe]"):
+        assert word not in strings, word
+    csrc = os.path.join(ROOT, "adaptigraph_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip") and f != "ag_diag.hip":
+            text = open(os.path.join(csrc, f)).read()
+            assert "atexit" not in text, f
+            assert text.count("getenv(") == (1 if f == "ag_api.hip" else 0), (f, text.count("getenv("))
+    diag = os.path.join(csrc, "libadaptigraph_hip_diag.so")
+    if os.path.exists(diag):                                             # same C-ABI, probes inside
+        d = subprocess.run(["nm", "-D", "--defined-only", diag], capture_output=True, text=True).stdout
+        assert sorted(set(re.findall(r" T (ag_[a-z_]+)$", d, flags=re.M))) == sorted(_lib.EXPORTS)
+        assert "AG_NODE_PROBE" in subprocess.run(["strings", "-n", "6", diag], capture_output=True, text=True).stdout
 
 
 def test_no_cpu_fallback():

@@ -46,24 +46,6 @@ def O():
     return adaptigraph_oracle
 
 
-class _env:
-    """os.environ override that the C side sees through getenv (AG_STREAMS is read on every call)."""
-
-    def __init__(self, **kw):
-        self.kw = kw
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kw}
-        os.environ.update({k: str(v) for k, v in self.kw.items()})
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
 def _chunk_plan(B, N, streams=2):
     """Mirror of ag_rollout_async's launch plan (csrc/ag_api.hip: auto_chunk + equal-chunk re-division) for the default
     settings - used only to pick WHICH candidates to hand to the oracle (first and last of every chunk)."""
@@ -213,10 +195,10 @@ def test_two_stream_multi_chunk_path_vs_oracle_and_one_stream(ag, O, dev):
     ppm = _ppm(task, "cloth")
     eng = m.engine(dev)
     eng.set_chunk(0)
-    with _env(AG_STREAMS=2):
+    with eng.options(streams=2):
         two = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]
     assert torch.isfinite(two).all()
-    with _env(AG_STREAMS=1):
+    with eng.options(streams=1):
         one = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]
         eng.set_chunk(37)                                               # odd chunk size, short last chunk, one stream
         odd = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]

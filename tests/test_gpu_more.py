@@ -576,34 +576,61 @@ def test_forward_on_overflowed_edgelist_raises_instead_of_faulting(ag, O, dev):
     assert torch.isfinite(pos).all()
 
 
-def test_failed_rollout_joins_its_streams_and_leaves_the_ctx_usable(ag, O, dev):
-    """A failure in the middle of the chunk loop (after the fork onto the second stream) must join the streams back;
-    the next rollout on the same ctx equals a fresh ctx's bit for bit."""
-    import os
-    rng = np.random.default_rng(29)
-    task = _task("cloth")
-    W, m = _model(ag, O, "cloth", 29, dev)
-    cloud = _grid(40, 0.3, 0.02, rng)                                   # 96 x 1601 rows: two streams
-    a = torch.from_numpy(_actions(cloud, 96, 1, 2, rng, spread=2.0)).to(dev)
-    s0 = torch.from_numpy(cloud).to(dev)
-    good = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"].clone()
-    os.environ["AG_TEST_FAIL_AT_CHUNK"] = "1"
-    try:
-        with pytest.raises(RuntimeError, match="injected failure"):
-            ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))
-    finally:
-        del os.environ["AG_TEST_FAIL_AT_CHUNK"]
-    torch.cuda.synchronize()                                            # nothing of the failed call is left in flight
-    again = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"]
-    assert torch.equal(again, good)
-    _, fresh = _model(ag, O, "cloth", 29, dev)
-    assert torch.equal(ag.dynamics(s0, a, fresh, dev, _ppm(task, "cloth"))["state_seqs"], good)
+_FAIL_CHILD = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, sys.argv[1])
+import adaptigraph_amd as ag
+from adaptigraph_amd import _lib
+from oracle import adaptigraph_oracle as O
+from test_gpu_parity import _ppm
+from test_gpu_more import _task, _grid, _actions, _model
+assert _lib.LIB_PATH.endswith("_diag.so")
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(29)
+task = _task("cloth")
+cloud = _grid(40, 0.3, 0.02, rng)                                       # 96 x 1601 rows: two streams
+a = torch.from_numpy(_actions(cloud, 96, 1, 2, rng, spread=2.0)).to(dev)
+s0 = torch.from_numpy(cloud).to(dev)
+os.environ.pop("AG_TEST_FAIL_AT_CHUNK", None)
+_, m = _model(ag, O, "cloth", 29, dev)                                  # context created WITHOUT the hook
+good = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"].clone()
+os.environ["AG_TEST_FAIL_AT_CHUNK"] = "1"                              # the hook is read when a context is created
+_, bad = _model(ag, O, "cloth", 29, dev)
+del os.environ["AG_TEST_FAIL_AT_CHUNK"]
+try:
+    ag.dynamics(s0, a, bad, dev, _ppm(task, "cloth"))
+    sys.exit("no failure was injected")
+except RuntimeError as e:
+    assert "injected failure" in str(e), e
+torch.cuda.synchronize()                                                # nothing of the failed call is left in flight
+# the failed context itself must be usable: it is driven again with a batch of one chunk (chunk 1 is never reached)
+one = ag.dynamics(s0, a[:40], bad, dev, _ppm(task, "cloth"))["state_seqs"]
+assert torch.equal(one, good[:40])
+again = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"]  # and the other context of the process is unaffected
+assert torch.equal(again, good)
+print("CHILD_OK")
+'''
+
+
+def test_failed_rollout_joins_its_streams_and_leaves_the_ctx_usable(dev):
+    """A failure in the middle of the chunk loop (after the fork onto the second stream) must join the streams back; the
+    failed context stays usable and a second context of the process is untouched.  The failure is injected by the
+    DIAGNOSTIC build of the library (-DAG_DIAG, AG_TEST_FAIL_AT_CHUNK; the product library has no such hook), loaded in a
+    child process through ADAPTIGRAPH_AMD_LIB."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "adaptigraph_amd", "csrc", "libadaptigraph_hip_diag.so")
+    assert os.path.exists(diag), "build the diagnostic library: adaptigraph_amd/csrc/build.sh diag"
+    env = dict(os.environ, ADAPTIGRAPH_AMD_LIB=diag)
+    r = subprocess.run([sys.executable, "-c", _FAIL_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CHILD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("topk", [10, 500])
 def test_ragged_row_list_equals_dense_rows_bitwise(ag, O, dev, topk):
     """Masked batches run the propagate chains over a compact row list + one phantom candidate for the masked-out
-    particles; AG_NO_RAGGED=1 runs all B x N rows as before.  Same bits for EVERY row, masked-out ones included (the
+    particles; option ragged=0 runs all B x N rows as before.  Same bits for EVERY row, masked-out ones included (the
     reference moves those too, model.py:338), with masks that have holes, an all-valid and a nearly empty candidate;
     topk 500 takes the CSR (radius-only) graph path."""
     import os
@@ -622,11 +649,8 @@ def test_ragged_row_list_equals_dense_rows_bitwise(ag, O, dev, topk):
     a = _actions(state[0], B, 1, [3, 2, 4, 1, 5, 2, 3], rng)[:, 0]
     args = (torch.from_numpy(state).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(a).to(dev))
     ragged = ag.dynamics_masked(*args, m, dev, _ppm(task, "rope"))["state_seqs"]
-    os.environ["AG_NO_RAGGED"] = "1"
-    try:
+    with m.engine(dev).options(ragged=0):
         dense = ag.dynamics_masked(*args, m, dev, _ppm(task, "rope"))["state_seqs"]
-    finally:
-        del os.environ["AG_NO_RAGGED"]
     assert torch.isfinite(ragged).all() and torch.equal(ragged, dense)
     m.engine(dev).set_chunk(3)                                          # phantom slot moves with the chunk size
     try:
@@ -657,11 +681,8 @@ def test_latency_kernels_equal_throughput_kernels_bitwise(ag, O, dev, material, 
     s0 = torch.from_numpy(cloud).to(dev)
     out = {}
     for mode in ("0", "1"):
-        os.environ["AG_LATENCY"] = mode
-        try:
+        with m.engine(dev).options(latency=int(mode)):
             out[mode] = ag.dynamics(s0, a, m, dev, _ppm(task, material))["state_seqs"]
-        finally:
-            del os.environ["AG_LATENCY"]
     assert torch.isfinite(out["1"]).all()
     assert torch.equal(out["0"], out["1"])
     auto = ag.dynamics(s0, a, m, dev, _ppm(task, material))["state_seqs"]      # by size: latency mode here
@@ -678,7 +699,7 @@ def test_latency_kernels_equal_throughput_kernels_bitwise(ag, O, dev, material, 
 ])
 def test_edge_block_schedule_equals_row_schedule_bitwise(ag, dev, N_o, M, topk, thr, pitch, cta):
     """Large batches build the top-k graph 64 receiver rows per wavefront (one row per lane, hit masks + per-lane sorted
-    top-k: csrc/ag_edges.hip block_topk); AG_EDGE_BLOCK_MIN switches back to one row per wavefront.  Same edge lists,
+    top-k: csrc/ag_edges.hip block_topk); option edge_block_min switches back to one row per wavefront.  Same edge lists,
     same CSR, same degrees - with holes in the masks, an empty candidate tail, far-away tools and exact distance ties."""
     import os
     rng = np.random.default_rng(N_o + topk)
@@ -703,13 +724,10 @@ def test_edge_block_schedule_equals_row_schedule_bitwise(ag, dev, N_o, M, topk, 
             states[b, N_o:, 0] += 1e3                            # tool out of reach: connect_tools_all flag stays off
     args = (torch.from_numpy(states).to(dev), thr, torch.from_numpy(mask).to(dev), torch.from_numpy(tool).to(dev), topk, cta)
     out = {}
-    for mode, val in (("blocks", "1"), ("rows", "1000000000")):
-        os.environ["AG_EDGE_BLOCK_MIN"] = val
-        try:
+    for mode, val in (("blocks", 1), ("rows", 1000000000)):
+        with ag.default_engine(dev).options(edge_block_min=val):
             el = ag.construct_edges_index(*args)
             out[mode] = [t.cpu().numpy().copy() for t in (el.n_edges, el.recv, el.send, el.row_ptr)]
-        finally:
-            os.environ.pop("AG_EDGE_BLOCK_MIN", None)
     n = out["rows"][0]
     assert n.min() > 0 and np.array_equal(out["blocks"][0], n)
     assert np.array_equal(out["blocks"][3], out["rows"][3])
@@ -780,7 +798,7 @@ def test_planner_class_chunk_loop_equals_chunked_entry_on_the_engine(ag, O, dev)
 
 
 def test_edge_chain_persistent_workgroups_equal_one_workgroup_per_tile_bitwise(ag, O, dev):
-    """AG_ENC_PERSIST=n runs k_edge_enc with n persistent workgroups walking the tiles (a measured-and-documented knob,
+    """Option enc_persist=n runs k_edge_enc with n persistent workgroups walking the tiles (a measured-and-documented knob,
     DESIGN.md section 3.1); rows are independent columns of the MFMA, so the result must not change - also when n does not
     divide the tile count and some workgroups get one tile more."""
     import os
@@ -790,15 +808,90 @@ def test_edge_chain_persistent_workgroups_equal_one_workgroup_per_tile_bitwise(a
     cloud = _grid(20, 0.3, 0.02, rng)
     a = torch.from_numpy(_actions(cloud, 12, 2, [[2, 1]] * 12, rng)).to(dev)
     s0 = torch.from_numpy(cloud).to(dev)
-    os.environ["AG_LATENCY"] = "0"                                       # throughput chains at this size
-    try:
+    eng = m.engine(dev)
+    with eng.options(latency=0):                                         # throughput chains at this size
         ref = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"]
-        for n in ("7", "64"):
-            os.environ["AG_ENC_PERSIST"] = n
-            try:
+        for n in (7, 64):
+            with eng.options(enc_persist=n):
                 got = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"]
-            finally:
-                del os.environ["AG_ENC_PERSIST"]
             assert torch.isfinite(got).all() and torch.equal(got, ref), n
-    finally:
-        del os.environ["AG_LATENCY"]
+
+
+# ------------------------------------------------------------------------------------------------- repeat-aware launch order
+@pytest.mark.parametrize("material,cloud_fn,B,H", [
+    ("rope", lambda r: _rope(200, r), 500, 1),                          # the shipped planner's chunk: 500 x (200+1), H = 1
+    ("cloth", lambda r: _grid(30, 0.3, 0.02, r), 150, 2),               # 150 x 901 rows: two streams, H = 2
+])
+def test_repeat_sorted_launch_order_is_bit_identical_and_runs_no_surplus_forward(ag, O, dev, material, cloud_fn, B, H):
+    """ag_rollout orders the candidates of a launch chunk by action_repeat and launches every step over the prefix that is
+    still live; option repeat_sort=0 steps every candidate of a chunk to the chunk maximum (the reference steps the whole
+    batch to the batch maximum and discards the surplus, forward_dynamics.py:156-161).  Candidates are independent, so the
+    outputs must be identical bit for bit - mixed repeats 2..15 (incl. a repeat of 0), one / two streams, several chunks -
+    and the executed candidate-forwards must equal sum(action_repeat)."""
+    rng = np.random.default_rng(97)
+    task = _task(material, max_nR=40000)
+    W, m = _model(ag, O, material, 97, dev)
+    cloud = cloud_fn(rng)
+    reps = rng.integers(2, 16, (B, H))
+    if H == 1:
+        reps[3, 0] = 0                                                  # never live: its slot stays zero (:32,:160)
+    a_np = _actions(cloud, B, H, reps, rng, spread=0.8)
+    if H == 1:
+        a_np[3, 0, 3] = 0.5
+    s0, a = torch.from_numpy(cloud).to(dev), torch.from_numpy(a_np).to(dev)
+    ppm = _ppm(task, material)
+    eng = m.engine(dev)
+    need = int(reps.sum())
+    outs = {}
+    for streams in (1, 2):
+        for chunk in (0, 37):
+            with eng.options(streams=streams):
+                eng.set_chunk(chunk)
+                try:
+                    got = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]
+                    ex, nd = eng.rollout_counts()
+                    assert nd == need and ex == need, (streams, chunk, ex, nd, need)
+                    with eng.options(repeat_sort=0):
+                        ref = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]
+                        ex0, nd0 = eng.rollout_counts()
+                finally:
+                    eng.set_chunk(0)
+            assert nd0 == need and ex0 > need                            # the surplus the sorted order does not run
+            assert torch.isfinite(got).all() and torch.equal(got, ref), (streams, chunk)
+            outs[(streams, chunk)] = got
+    first = outs[(1, 0)]
+    assert all(torch.equal(first, o) for o in outs.values())
+    if H == 1:
+        assert float(first[3, 0].abs().max()) == 0.0
+    print(f"{material}: sum(action_repeat) = {need} candidate-forwards; unsorted order executed {ex0} ({ex0 / need:.2f}x)")
+    picks = [0, 3, B - 1]
+    want = O.dynamics(W, 3, cloud, a_np[picks], task)["state_seqs"]
+    err = np.abs(first[picks].cpu().numpy() - want).reshape(len(picks), -1).max(1)
+    assert (err <= POS_TOL).sum() >= 2, err                             # (a long free-running rollout may pass a near-tie)
+
+
+def test_two_contexts_in_one_process_keep_their_own_options(ag, O, dev):
+    """Options live in the context (environment defaults are read once, at ag_ctx_create): two models with different
+    switches run side by side, each on its own path, and agree bit for bit."""
+    rng = np.random.default_rng(99)
+    task = _task("rope")
+    W, m1 = _model(ag, O, "rope", 99, dev)
+    _, m2 = _model(ag, O, "rope", 99, dev)
+    cloud = _rope(150, rng)
+    reps = rng.integers(1, 6, (40, 1))
+    a = torch.from_numpy(_actions(cloud, 40, 1, reps, rng)).to(dev)
+    s0 = torch.from_numpy(cloud).to(dev)
+    e1, e2 = m1.engine(dev), m2.engine(dev)
+    assert e1.ctx.value != e2.ctx.value
+    e1.set_option("repeat_sort", 0); e1.set_option("latency", 0); e1.set_option("self_dedupe", 0); e1.set_option("stagger_us", 30)
+    assert (e1.get_option("repeat_sort"), e2.get_option("repeat_sort")) == (0, 1)
+    assert (e1.get_option("latency"), e2.get_option("latency")) == (0, -1)
+    o1 = ag.dynamics(s0, a, m1, dev, _ppm(task, "rope"))["state_seqs"]
+    o2 = ag.dynamics(s0, a, m2, dev, _ppm(task, "rope"))["state_seqs"]
+    o1b = ag.dynamics(s0, a, m1, dev, _ppm(task, "rope"))["state_seqs"]
+    assert torch.equal(o1, o2) and torch.equal(o1, o1b)
+    x1, n1 = e1.rollout_counts()
+    x2, n2 = e2.rollout_counts()
+    assert n1 == n2 == int(reps.sum()) and x2 == n2 and x1 == 40 * int(reps.max())
+    with pytest.raises(AssertionError, match="unknown option"):
+        e1.set_option("no_such_switch", 1)

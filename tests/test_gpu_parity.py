@@ -61,12 +61,14 @@ def _edges_to_lists(el):
 
 # ------------------------------------------------------------------------------------------------- edges
 @pytest.fixture(params=["auto", "rows", "blocks"])
-def edge_path(request, monkeypatch):
+def edge_path(request, ag, dev):
     """The top-k builder has two row schedules with identical results: one receiver row per wavefront, and 64 rows per
-    wavefront (taken for slices of >= 256 rows).  AG_EDGE_BLOCK_MIN forces either one at any slice size."""
-    if request.param != "auto":
-        monkeypatch.setenv("AG_EDGE_BLOCK_MIN", "1" if request.param == "blocks" else "1000000000")
-    return request.param
+    wavefront (taken for slices of >= 256 rows).  Option edge_block_min forces either one at any slice size."""
+    if request.param == "auto":
+        yield request.param
+        return
+    with ag.default_engine(dev).options(edge_block_min=1 if request.param == "blocks" else 1000000000):
+        yield request.param
 
 
 def test_edges_vs_reference_golden(ag, dev, edge_path):

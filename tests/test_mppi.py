@@ -86,3 +86,32 @@ def test_mppi_sampler_seeded_like_the_reference_and_update_properties():
     sharp = ag.optimize_action_mppi(a, rew, 1e9, lo, hi, 0.1)           # softmax collapses onto the best candidate
     want = ag.clip_actions(a[best], lo, hi)
     assert float((sharp - want).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_nan_rewards_and_actions_surface_as_nan_like_the_reference():
+    """The reference's softmax / clamp_ propagate NaN (plan_utils.py:31-39, 83): one NaN reward makes the whole updated
+    action NaN; a NaN component of an action stays NaN through clip_actions.  A device clamp spelled fmin(fmax()) would
+    return the lower limit instead - a valid-looking action."""
+    import adaptigraph_amd as ag
+    dev = torch.device("cuda:0")
+    g = load_golden("mppi")
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    lo, hi = t("lo"), t("hi")
+    nan = float("nan")
+    assert torch.isnan(torch.clamp(torch.tensor([nan]), -1.0, 1.0)).all()              # the reference's semantics (CPU torch)
+    assert torch.isnan(torch.softmax(torch.tensor([0.0, nan, 1.0]), 0)).all()
+    rew = t("rewards").clone()
+    rew[17] = nan
+    up = ag.optimize_action_mppi(t("sample_iter1"), rew, 500.0, lo, hi, 0.1)
+    assert torch.isnan(up).all()
+    wild = t("wild").clone()
+    wild[1, 2, 0] = nan
+    wild[2, 0, 2] = nan
+    cl = ag.clip_actions(wild, lo, hi)
+    want = torch.from_numpy(g["clipped"]).to(dev)
+    bad = torch.zeros_like(wild, dtype=torch.bool)
+    bad[1, 2, 0] = True
+    bad[2, 0, 2] = True
+    assert torch.isnan(cl[bad]).all() and not torch.isnan(cl[~bad]).any()
+    assert float((cl[~bad] - want[~bad]).abs().max()) <= 1e-5

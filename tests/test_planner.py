@@ -134,6 +134,27 @@ def _chunk_worker(rank, world, port, q):
     res = pl.trajectory_optimization_chunked(state_cur, act0.clone(), 5)          # 3 + 2 chunks
     ok = np.array_equal(res["act_seq"].numpy(), g["d_act_seq"]) and \
         np.array_equal(res["best_eval_output"]["reward_seqs"].numpy(), g["d_best_reward"])
+    # an evaluation that would all-reduce inside every call (built with group=..., as mpc_iteration wants it) is refused
+    # BEFORE any rank enters it: the ranks evaluate 3 and 2 chunks, the collectives would not pair up (a hang)
+    from functools import partial
+
+    def cost_with_collective(state_seqs, act_seqs, state_cur=None, group=None, **kw):
+        if group is not None:
+            dist.all_reduce(torch.zeros(1))
+        return toy_cost(state_seqs, act_seqs, state_cur=state_cur)
+    bad = _planner(n_update_iter=1, group=True, evaluate_traj_fn=partial(cost_with_collective, group=True))
+    try:
+        bad.trajectory_optimization_chunked(state_cur, act0.clone(), 5)
+        ok = False
+    except ValueError as e:
+        ok = ok and "rank-local" in str(e)
+    nested = _planner(n_update_iter=1, group=True,
+                      evaluate_traj_fn=partial(toy_cost, penalty_func=partial(cost_with_collective, group=True)))
+    try:
+        nested.trajectory_optimization_chunked(state_cur, act0.clone(), 5)
+        ok = False
+    except ValueError:
+        pass
     q.put((rank, bool(ok), calls))
     dist.destroy_process_group()
 
