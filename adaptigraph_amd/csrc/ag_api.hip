@@ -64,6 +64,8 @@ struct ag_ctx {
     int* d_repeat = nullptr; size_t repeat_cap = 0;   // device: [repeat (B*H) | launch order (H*B)]
     std::vector<int> h_repeat;   // ctx-owned copy so the caller's array may die right after the call; same layout
     long long fwd_executed = 0, fwd_needed = 0;       // candidate-forwards of the last rollout call (ag_ctx_rollout_counts)
+    char* d_plan = nullptr; size_t plan_cap = 0;      // device-planned rollouts (ag_rollout_actions): decoded tool keypoints,
+    int* d_plan_sums = nullptr; int plan_sums_n = 0;  // repeats, launch order and per-step live counts; sums pending a read-back
     int* d_overflow = nullptr;
     float* d_cself = nullptr;    // (256, NFP): rows 0/1 = C of an object / tool self-loop edge (see GraphBufs)
     // second in-library stream: alternate chunks run on it so that the HBM-bound kernels of one chunk overlap the
@@ -493,6 +495,7 @@ int ag_ctx_destroy(ag_ctx* c) {
     if (c->d_overflow) (void)hipFree(c->d_overflow);
     if (c->d_cself) (void)hipFree(c->d_cself);
     if (c->d_repeat) (void)hipFree(c->d_repeat);
+    if (c->d_plan) (void)hipFree(c->d_plan);
     if (c->slab.base) (void)hipFree(c->slab.base);
     delete c;
     return AG_OK;
@@ -529,6 +532,15 @@ int ag_ctx_get_option(ag_ctx* c, const char* name, int32_t* out) {
 
 int ag_ctx_rollout_counts(ag_ctx* c, int64_t* out_executed, int64_t* out_needed) {
     if (!c || !out_executed || !out_needed) return AG_ERR_INVALID;
+    if (c->d_plan_sums) {                                    // device-planned call: the sums are still on the device
+        std::vector<int> h((size_t)c->plan_sums_n * 2);
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, hipMemcpy(h.data(), c->d_plan_sums, h.size() * 4, hipMemcpyDeviceToHost));
+        c->fwd_needed = 0; c->fwd_executed = 0;
+        for (int i = 0; i < c->plan_sums_n; ++i) { c->fwd_needed += h[2 * i]; c->fwd_executed += h[2 * i + 1]; }
+        c->d_plan_sums = nullptr;
+    }
     *out_executed = c->fwd_executed; *out_needed = c->fwd_needed;
     return AG_OK;
 }
@@ -736,13 +748,30 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
     return AG_OK;
 }
 
-int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0,
-                     const uint8_t* d_obj_mask, const float* d_eef_xz, const float* d_eef_delta,
-                     const int32_t* h_repeat, const float* d_phys_vec, float* d_state_seqs, int32_t* d_overflow_flag) {
+}  // extern "C"
+
+namespace {
+// where a rollout's actions come from: decoded on the host by the caller (ag_rollout / ag_rollout_async), or raw on the
+// device (ag_rollout_actions: decode + launch plan by k_roll_plan, the host never sees them)
+struct ActionSrc {
+    const float* d_eef_xz = nullptr; const float* d_eef_delta = nullptr; const int32_t* h_repeat = nullptr;   // host plan
+    const float* d_action = nullptr; float push_length = 0.f; const float* h_tool_off = nullptr; int max_repeat = 0;
+    float* d_action_seqs = nullptr;                                                                            // device plan
+};
+
+int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0, const uint8_t* d_obj_mask,
+                 const ActionSrc& src, const float* d_phys_vec, float* d_state_seqs, int32_t* d_overflow_flag) {
+    const bool dev_plan = src.d_action != nullptr;
+    const float* d_eef_xz = src.d_eef_xz; const float* d_eef_delta = src.d_eef_delta; const int32_t* h_repeat = src.h_repeat;
     if (!c) return AG_ERR_INVALID;
     if (!c->have_w) return fail(c, AG_ERR_NO_WEIGHTS, "ag_rollout before ag_ctx_load_weights");
-    if (!p || !d_state0 || !d_eef_xz || !d_eef_delta || !h_repeat || !d_state_seqs || !d_overflow_flag)
+    if (!p || !d_state0 || !d_state_seqs || !d_overflow_flag || (!dev_plan && (!d_eef_xz || !d_eef_delta || !h_repeat)) ||
+        (dev_plan && (!src.d_action_seqs || (p->M > 1 && !src.h_tool_off))))
         return fail(c, AG_ERR_INVALID, "ag_rollout: null pointer");
+    if (dev_plan && (src.max_repeat < 0 || src.max_repeat > 1024 || p->M > 8))
+        return fail(c, AG_ERR_INVALID, "ag_rollout_actions: max_repeat must be in [0, 1024] and M <= 8 (got %d, %d)", src.max_repeat, p->M);
+    if (dev_plan && p->y_mode != 0)
+        return fail(c, AG_ERR_UNSUPPORTED, "ag_rollout_actions serves dynamics() (y_mode 0); the masked variant takes host-decoded actions");
     if (p->B < 1 || p->H < 1 || p->N_o < 1 || p->M < 1 || p->max_nR < 1)
         return fail(c, AG_ERR_INVALID, "ag_rollout: bad sizes B=%d H=%d N_o=%d M=%d max_nR=%d", p->B, p->H, p->N_o, p->M, p->max_nR);
     if (p->y_mode != 0 && p->y_mode != 1) return fail(c, AG_ERR_INVALID, "y_mode must be 0 or 1");
@@ -807,27 +836,63 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     // reads by candidate id.  Candidates are independent, so every candidate's result is bit-identical to the unsorted
     // order's.  Ragged batches keep their slot order (their row list is built once per call).
     const bool sort_on = c->opt.repeat_sort && !ragged;
-    if (c->repeat_cap < 2 * nrep) {
-        if (c->d_repeat) HIPCHK(c, hipFree(c->d_repeat));
-        c->d_repeat = nullptr; c->repeat_cap = 0;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_repeat), 2 * nrep * 4));
-        c->repeat_cap = 2 * nrep;
-    }
-    c->h_repeat.resize(2 * nrep);
-    std::copy(h_repeat, h_repeat + nrep, c->h_repeat.begin());
-    h_repeat = c->h_repeat.data();
-    int* h_cand = c->h_repeat.data() + nrep;                 // [li][slot] -> candidate
-    for (int li = 0; li < p->H; ++li)
-        for (int b0 = 0; b0 < p->B; b0 += Bc) {
-            const int nb = std::min(Bc, p->B - b0);
-            int* seg = h_cand + (size_t)li * p->B + b0;
-            for (int b = 0; b < nb; ++b) seg[b] = b0 + b;
-            if (sort_on)
-                std::stable_sort(seg, seg + nb, [&](int x, int y) { return h_repeat[(size_t)x * p->H + li] > h_repeat[(size_t)y * p->H + li]; });
+    const int n_chunks_all = (p->B + Bc - 1) / Bc;
+    int* h_cand = nullptr;
+    // device plan: pointers into c->d_plan
+    const int R = src.max_repeat;
+    int *pl_repeat = nullptr, *pl_cand = nullptr, *pl_live = nullptr, *pl_rows = nullptr, *pl_sums = nullptr;
+    float *pl_xz = nullptr, *pl_delta = nullptr;
+    c->d_plan_sums = nullptr;
+    if (!dev_plan) {
+        if (c->repeat_cap < 2 * nrep) {
+            if (c->d_repeat) HIPCHK(c, hipFree(c->d_repeat));
+            c->d_repeat = nullptr; c->repeat_cap = 0;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_repeat), 2 * nrep * 4));
+            c->repeat_cap = 2 * nrep;
         }
-    HIPCHK(c, hipMemcpyAsync(c->d_repeat, h_repeat, 2 * nrep * 4, hipMemcpyHostToDevice, st));
-    c->fwd_executed = 0; c->fwd_needed = 0;
-    for (size_t i = 0; i < nrep; ++i) c->fwd_needed += std::max(0, h_repeat[i]);
+        c->h_repeat.resize(2 * nrep);
+        std::copy(h_repeat, h_repeat + nrep, c->h_repeat.begin());
+        h_repeat = c->h_repeat.data();
+        h_cand = c->h_repeat.data() + nrep;                  // [li][slot] -> candidate
+        for (int li = 0; li < p->H; ++li)
+            for (int b0 = 0; b0 < p->B; b0 += Bc) {
+                const int nb = std::min(Bc, p->B - b0);
+                int* seg = h_cand + (size_t)li * p->B + b0;
+                for (int b = 0; b < nb; ++b) seg[b] = b0 + b;
+                if (sort_on)
+                    std::stable_sort(seg, seg + nb, [&](int x, int y) { return h_repeat[(size_t)x * p->H + li] > h_repeat[(size_t)y * p->H + li]; });
+            }
+        HIPCHK(c, hipMemcpyAsync(c->d_repeat, h_repeat, 2 * nrep * 4, hipMemcpyHostToDevice, st));
+        c->fwd_executed = 0; c->fwd_needed = 0;
+        for (size_t i = 0; i < nrep; ++i) c->fwd_needed += std::max(0, h_repeat[i]);
+    } else {
+        // Device plan: one kernel decodes the actions (plan_utils.py:11-20, forward_dynamics.py:42-75), orders every
+        // chunk's candidates by action_repeat and tabulates how many are live at every step; the launches below take their
+        // live counts from that table (device memory), so nothing of the actions ever crosses to the host.
+        const size_t tab = (size_t)n_chunks_all * p->H * (R + 2);
+        const size_t n_int = 2 * nrep + 2 * tab + (size_t)n_chunks_all * p->H * 2;
+        const size_t n_flt = nrep * p->M * 5;
+        const size_t bytes = round_up(n_int * 4, 256) + n_flt * 4;
+        if (c->plan_cap < bytes) {
+            if (c->d_plan) HIPCHK(c, hipFree(c->d_plan));
+            c->d_plan = nullptr; c->plan_cap = 0;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_plan), bytes + (bytes >> 2)));
+            c->plan_cap = bytes + (bytes >> 2);
+        }
+        pl_repeat = reinterpret_cast<int*>(c->d_plan); pl_cand = pl_repeat + nrep; pl_live = pl_cand + nrep;
+        pl_rows = pl_live + tab; pl_sums = pl_rows + tab;
+        pl_xz = reinterpret_cast<float*>(c->d_plan + round_up(n_int * 4, 256)); pl_delta = pl_xz + nrep * p->M * 2;
+        RollPlan rp{};
+        rp.action = src.d_action; rp.push_length = src.push_length; rp.M = p->M;
+        for (int kk = 1; kk < p->M; ++kk) rp.tool_off[kk] = src.h_tool_off[kk];
+        rp.B = p->B; rp.H = p->H; rp.Bc = Bc; rp.N = N; rp.max_repeat = R;
+        rp.decoded = src.d_action_seqs; rp.eef_xz = pl_xz; rp.eef_delta = pl_delta; rp.repeat = pl_repeat; rp.cand = pl_cand;
+        rp.live = pl_live; rp.rows = pl_rows; rp.sums = pl_sums; rp.flags = d_overflow_flag; rp.sort = sort_on ? 1 : 0;
+        HIPCHK(c, launch_roll_plan(rp, st));
+        d_eef_xz = pl_xz; d_eef_delta = pl_delta;
+        c->d_plan_sums = pl_sums; c->plan_sums_n = n_chunks_all * p->H;
+        c->fwd_executed = -1; c->fwd_needed = -1;
+    }
 
     const size_t wb = work_bytes(Ba, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
     rc = ensure_slab(c, wb * ns);
@@ -878,7 +943,7 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
         ra.B = nb; ra.N_o = p->N_o; ra.M = p->M; ra.H = p->H; ra.y_mode = p->y_mode; ra.b0 = b0;
         ra.grip = p->gripper_offset; ra.grip_on = p->gripper_enable; ra.phys = p->physics_param; ra.phys_vec = d_phys_vec;
         ra.state0 = d_state0; ra.state0_batched = p->y_mode == 1; ra.obj_mask = d_obj_mask;
-        ra.eef_xz = d_eef_xz; ra.eef_delta = d_eef_delta; ra.repeat = c->d_repeat; ra.state_seqs = d_state_seqs;
+        ra.eef_xz = d_eef_xz; ra.eef_delta = d_eef_delta; ra.repeat = dev_plan ? pl_repeat : c->d_repeat; ra.state_seqs = d_state_seqs;
         EdgeArgs ea{};
         ea.pos = w.r.hist + (size_t)(N_HIS - 1) * N * 3; ea.pos_bstride = (long)N_HIS * N * 3;
         ea.mask = w.r.mask; ea.tool = w.r.tool; ea.thr_vec = nullptr; ea.thr = p->adj_thresh;
@@ -898,11 +963,13 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
             g.rowlist = w.rowlist; g.n_rows = w.n_rows;
         }
         for (int li = 0; li < p->H; ++li) {
-            const int* seg = h_cand + (size_t)li * p->B + b0;    // slot -> candidate of this chunk and look-ahead step
-            int max_rep = 0;
-            for (int b = 0; b < nb; ++b) max_rep = std::max(max_rep, h_repeat[(size_t)seg[b] * p->H + li]);
-            ra.li = li; ra.ai = 0; ra.B = nb;
-            ra.cand = sort_on ? c->d_repeat + nrep + (size_t)li * p->B + b0 : nullptr;
+            const int* seg = dev_plan ? nullptr : h_cand + (size_t)li * p->B + b0;   // slot -> candidate of this chunk and look-ahead step
+            int max_rep = dev_plan ? R : 0;                  // device plan: the caller's bound; steps past a chunk's own maximum find no live slot
+            if (!dev_plan) for (int b = 0; b < nb; ++b) max_rep = std::max(max_rep, h_repeat[(size_t)seg[b] * p->H + li]);
+            ra.li = li; ra.ai = 0; ra.B = nb; ra.live = nullptr;
+            ra.cand = dev_plan ? pl_cand + (size_t)li * p->B + b0 : sort_on ? c->d_repeat + nrep + (size_t)li * p->B + b0 : nullptr;
+            const int* live_row = dev_plan ? pl_live + ((size_t)ci * p->H + li) * (R + 2) : nullptr;
+            const int* rows_row = dev_plan ? pl_rows + ((size_t)ci * p->H + li) * (R + 2) : nullptr;
             // masked variant: the object rows depend on nothing per-candidate either (both validity variants are
             // tabulated), so they are encoded once per call and workspace; tool rows once per look-ahead step
             ra.write_obj_cls = obj_cls_ready[ci % ns] ? 0 : 1;
@@ -914,11 +981,15 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
             obj_cls_ready[ci % ns] = true;
             int n_live = nb;
             for (int ai = 1; ai <= max_rep; ++ai) {           // forward_dynamics.py:156
-                if (sort_on) while (n_live > 0 && h_repeat[(size_t)seg[n_live - 1] * p->H + li] < ai) --n_live;   // descending order: a prefix
+                if (dev_plan) {   // grids cover the whole chunk; the kernels read how many slots are live from the plan's table
+                    ea.live = live_row + ai; ra.live = live_row + ai; g.n_rows = rows_row + ai;
+                } else {
+                    if (sort_on) while (n_live > 0 && h_repeat[(size_t)seg[n_live - 1] * p->H + li] < ai) --n_live;   // descending order: a prefix
+                    c->fwd_executed += n_live;
+                }
                 ea.B = n_live; g.B = n_live; ra.B = n_live;
-                c->fwd_executed += n_live;
                 HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));
-                if (g.ns_edge && !ell_full) { Scoped s(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, n_live, N, edge_cap, w.ns_edge, w.n_ns, cs)); }
+                if (g.ns_edge && !ell_full) { Scoped s(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, n_live, N, edge_cap, w.ns_edge, w.n_ns, ea.live, cs)); }
                 rc = run_model(c, g, w.r.pred, w.r.motion, cs);
                 if (rc) return rc;
                 ra.ai = ai;
@@ -938,6 +1009,29 @@ int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const 
     }
     c->prof_stream = st;
     return rc_loop ? rc_loop : rc_join;
+}
+}  // namespace
+
+extern "C" {
+
+int ag_rollout_async(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0,
+                     const uint8_t* d_obj_mask, const float* d_eef_xz, const float* d_eef_delta,
+                     const int32_t* h_repeat, const float* d_phys_vec, float* d_state_seqs, int32_t* d_overflow_flag) {
+    ActionSrc src;
+    src.d_eef_xz = d_eef_xz; src.d_eef_delta = d_eef_delta; src.h_repeat = h_repeat;
+    if (c && (!d_eef_xz || !d_eef_delta || !h_repeat)) return fail(c, AG_ERR_INVALID, "ag_rollout: null pointer");
+    return rollout_impl(c, stream, p, d_state0, d_obj_mask, src, d_phys_vec, d_state_seqs, d_overflow_flag);
+}
+
+int ag_rollout_actions(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0, const float* d_action,
+                       float push_length, const float* h_tool_offsets, int32_t max_repeat, const float* d_phys_vec,
+                       float* d_state_seqs, float* d_action_seqs, int32_t* d_flags) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_action || !d_action_seqs || !d_flags) return fail(c, AG_ERR_INVALID, "ag_rollout_actions: null pointer");
+    ActionSrc src;
+    src.d_action = d_action; src.push_length = push_length; src.h_tool_off = h_tool_offsets; src.max_repeat = max_repeat;
+    src.d_action_seqs = d_action_seqs;
+    return rollout_impl(c, stream, p, d_state0, nullptr, src, d_phys_vec, d_state_seqs, d_flags);
 }
 
 int ag_rollout(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0, const uint8_t* d_obj_mask,

@@ -78,7 +78,8 @@ struct Options {
     int edge_block_min = -1;  // [AG_EDGE_BLOCK_MIN] rows per slice from which the 64-rows-per-wavefront schedule is used (-1: built-in)
     int enc_persist = 0;      // [AG_ENC_PERSIST]    persistent workgroups of k_edge_enc (0 = one per tile)
     int stagger_us = 0;       // [AG_STAGGER_US]     offset between the two workgroups of a CU in the propagate chains
-    int device_decode = 0;    // [AG_DEVICE_DECODE]  read by the Python shim only (kept here so both sides list the same names)
+    int device_decode = -1;   // [AG_DEVICE_DECODE]  consumed by the Python shim: dynamics() hands GPU-resident actions to
+                              //                     ag_rollout_actions (-1: when the task config bounds the repeat, 0 never, 1 always)
 };
 
 // ---- launchers (defined in the .hip files) ------------------------------------------------------------
@@ -109,6 +110,8 @@ struct EdgeArgs {
     int ell_full; int ell_stride; long ell_bstride;   // 0 / unset: ell_stride = min(topk,N), ell_bstride = N*ell_stride
     int* ns_edge; int* n_ns;
     int block_min_rows;         // Options::edge_block_min (-1: built-in threshold)
+    const int* live;            // null, or device int: candidates [*live, B) of this launch have no forward left (device-planned
+                                // rollout, RollPlan): their workgroups exit and their graphs are presented as empty
 };
 hipError_t launch_edge_build(const EdgeArgs& a, hipStream_t st, void (*mark)(void*, int, int), void* mark_ctx);
 // list of non-self-loop edges per candidate (self-loop dedupe, see GraphBufs)
@@ -122,7 +125,7 @@ struct RuleArgs {
 };
 hipError_t launch_tool_rule(const RuleArgs& a, hipStream_t st);
 hipError_t launch_edge_nonself(const int* recv, const int* send, const int* row_ptr, int B, int N, int edge_cap,
-                               int* ns_edge, int* n_ns, hipStream_t st);
+                               int* ns_edge, int* n_ns, const int* live, hipStream_t st);
 
 struct GraphBufs {
     // per-chunk activations; node rows = b*N + i, edge rows = b*c_cap + e, pitch NFP floats
@@ -205,6 +208,7 @@ struct RollArgs {
     const uint8_t* obj_mask;                  // (Bfull,N_o) or null
     const float* eef_xz; const float* eef_delta;  // (Bfull,H,M,2), (Bfull,H,M,3)
     const int* repeat;                        // device (Bfull,H)
+    const int* live;                          // null, or device int: slots [*live, B) have no forward left (k_roll_update exits)
     const int* cand;                          // null, or (B,) device: slot b of this chunk holds candidate cand[b] of the full
                                               // batch (repeat-sorted launch order); null = candidate b0 + b
     float* state_seqs;                        // (Bfull,H,N_o,3)
@@ -223,6 +227,24 @@ hipError_t launch_mppi_sample(const float* act_seq, const float* lo, const float
 hipError_t launch_mppi_update(const float* acts, const float* reward, const float* lo, const float* hi, int B, int H,
                               float rw, float pl, float* out, hipStream_t st);
 hipError_t launch_mppi_clip(const float* in, const float* lo, const float* hi, float* out, long n, hipStream_t st);
+
+// Device-side launch plan of a rollout whose actions are resident on the GPU (ag_rollout_actions): decode_action + tool
+// keypoints (plan_utils.py:11-20, forward_dynamics.py:42-75) and the repeat-aware launch order, without the host ever seeing
+// an action.  One wavefront per (launch chunk, look-ahead step): decodes the chunk's actions, orders its candidates by
+// action_repeat (descending, stable) and tabulates for every step ai = 0..max_repeat how many of them are still live.
+struct RollPlan {
+    const float* action;        // (B,H,4) raw [x, z, theta, length]
+    float push_length; int M; float tool_off[8];   // pusher_points[k][1] * sim_real_ratio, k < M (entry 0 unused)
+    int B, H, Bc, N, max_repeat;
+    float* decoded;             // (B,H,4) [x_start, z_start, x_end, z_end]        -> action_seqs
+    float* eef_xz; float* eef_delta; int* repeat;  // (B,H,M,2), (B,H,M,3), (B,H)
+    int* cand;                  // (H,B) slot -> candidate, per chunk segment
+    int* live; int* rows;       // (n_chunks, H, max_repeat + 2): candidates live at step ai, and that times N
+    int* sums;                  // (n_chunks, H, 2): sum of min(repeat, max_repeat), sum of live over the steps
+    int* flags;                 // caller's flag words: [1] = atomicMax of a repeat beyond max_repeat
+    int sort;                   // 0: keep the candidate order (live counts then stay at the chunk size while any candidate is live)
+};
+hipError_t launch_roll_plan(const RollPlan& p, hipStream_t st);
 
 // work list of a ragged batch (see GraphBufs::rowlist): valid rows of candidates [0,B) + phantom rows if any particle is
 // masked out; also clears the phantom candidate's mask and degree rows

@@ -53,6 +53,7 @@ struct EdgeDev {
     int* deg; int* slice_tot; int* cta_flag;
     int* recv; int* send; int* row_ptr; int* n_edges; int* overflow; int max_nR; int zero_on_overflow;
     int block_min_rows;                  // slices with at least this many rows take the 64-rows-per-wavefront path
+    const int* live;                     // see EdgeArgs
 };
 
 __device__ __forceinline__ float dist_exact(float xi, float yi, float zi, float xj, float yj, float zj) {
@@ -475,6 +476,7 @@ __device__ int row_radius_count(const EdgeDev& a, const EdgeLds& l, int i, float
 __global__ __launch_bounds__(EW) void k_edge_count(EdgeDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / a.slices, sl = blockIdx.x % a.slices;
+    if (a.live && b >= *a.live) return;                     // device-planned rollout: this slot has no forward left
     const EdgeLds l = carve(smem, a.N);
     load_candidate(a, l, b, true);
     const float thr = thr_of(a, b);
@@ -548,6 +550,10 @@ __global__ __launch_bounds__(EW) void k_edge_count(EdgeDev a) {
 __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / a.slices, sl = blockIdx.x % a.slices;
+    if (a.live && b >= *a.live) {                           // no forward left: present an empty graph downstream
+        if (sl == 0 && threadIdx.x == 0) a.n_edges[b] = 0;
+        return;
+    }
     const EdgeLds l = carve(smem, a.N);
     load_candidate(a, l, b, !a.topk_active);
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -668,6 +674,10 @@ __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
 __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
     __shared__ int scan[EW];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (a.live && b >= *a.live) {                           // no forward left: nothing for the relation encoder to do
+        if (tid == 0) { a.n_ns[b] = 0; a.n_edges[b] = 0; }
+        return;
+    }
     int total = 0;
     for (int s = 0; s < a.slices; ++s) total += a.slice_tot[b * a.slices + s];
     const bool hide = total > a.max_nR && a.zero_on_overflow;   // downstream kernels then see an empty graph
@@ -720,7 +730,7 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     a.ell_bstride = a.ell_full ? h.ell_bstride : (long)h.N * a.k;
     a.ns_edge = h.ns_edge; a.n_ns = h.n_ns;
     a.recv = h.recv; a.send = h.send; a.row_ptr = h.row_ptr; a.n_edges = h.n_edges; a.overflow = h.overflow;
-    a.max_nR = h.max_nR; a.zero_on_overflow = h.zero_on_overflow;
+    a.max_nR = h.max_nR; a.zero_on_overflow = h.zero_on_overflow; a.live = h.live;
     a.block_min_rows = h.block_min_rows >= 0 ? h.block_min_rows : BLOCK_MIN_ROWS;   // A/B switch (Options::edge_block_min); results identical
     const size_t lds = edge_lds_bytes(h.N);
     // the > 64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: track it per device ordinal
@@ -749,9 +759,11 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
 // ---- non-self-loop edge list (self-loop dedupe).  One workgroup per candidate.  Row i has at most one self-loop;
 // S(i) = number of self-loops in rows < i (integer scan); the t-th non-self edge keeps the CSR order.
 __global__ __launch_bounds__(EW) void k_edge_nonself(const int* __restrict__ send_all, const int* __restrict__ row_ptr_all,
-                                                      int N, int edge_cap, int* __restrict__ ns_all, int* __restrict__ n_ns) {
+                                                      int N, int edge_cap, int* __restrict__ ns_all, int* __restrict__ n_ns,
+                                                      const int* __restrict__ live) {
     __shared__ int scan[EW];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (live && b >= *live) { if (tid == 0) n_ns[b] = 0; return; }
     const int* send = send_all + (long)b * edge_cap;
     const int* rp = row_ptr_all + (long)b * (N + 1);
     int* ns = ns_all + (long)b * edge_cap;
@@ -782,9 +794,9 @@ __global__ __launch_bounds__(EW) void k_edge_nonself(const int* __restrict__ sen
     if (tid == EW - 1) n_ns[b] = rp[N] - scan[EW - 1];
 }
 hipError_t launch_edge_nonself(const int* recv, const int* send, const int* row_ptr, int B, int N, int edge_cap,
-                               int* ns_edge, int* n_ns, hipStream_t st) {
+                               int* ns_edge, int* n_ns, const int* live, hipStream_t st) {
     (void)recv;
-    hipLaunchKernelGGL(k_edge_nonself, dim3(B), dim3(EW), 0, st, send, row_ptr, N, edge_cap, ns_edge, n_ns);
+    hipLaunchKernelGGL(k_edge_nonself, dim3(B), dim3(EW), 0, st, send, row_ptr, N, edge_cap, ns_edge, n_ns, live);
     return hipGetLastError();
 }
 

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(RT) void k_roll_update(RollDev d) {
     __shared__ float red[RT];
     __shared__ int redi[RT];
     const RollArgs& a = d.a;
+    if (a.live && (int)blockIdx.x >= *a.live) return;         // device-planned rollout: no forward was run for this slot
     const int b = blockIdx.x, bg = a.cand ? a.cand[b] : a.b0 + b, tid = threadIdx.x;
     const int N = a.N_o + a.M;
     float* pred = d.pred + (long)b * a.N_o * 3;
@@ -288,6 +289,96 @@ __global__ __launch_bounds__(RT) void k_build_rowlist(const uint8_t* __restrict_
 hipError_t launch_build_rowlist(const uint8_t* obj_mask, int b0, int B, int N_o, int M, int* rowlist, int* n_rows,
                                 uint8_t* mask, int* deg, hipStream_t st) {
     hipLaunchKernelGGL(k_build_rowlist, dim3(1), dim3(RT), 0, st, obj_mask, b0, B, N_o, M, rowlist, n_rows, mask, deg);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ device-side launch plan
+// See RollPlan (ag_common.h).  fp32 operations spelled in the reference's order (plan_utils.py:13-16: end = start -
+// push_length * (cos, sin); forward_dynamics.py:48-75: delta = end - start, side keypoints start +- c_k * (sin, cos)); the
+// transcendental functions are the device's (a GPU-resident reference would use the device's too), so decoded values agree
+// with a CPU decode to an ulp or two, not bit for bit.
+constexpr int PLAN_MAXR = 1024;
+__global__ __launch_bounds__(64) void k_roll_plan(RollPlan p) {
+    __shared__ int hist[PLAN_MAXR + 2];
+    __shared__ int base[PLAN_MAXR + 2];
+    const int lane = threadIdx.x;
+    const int n_chunks = (p.B + p.Bc - 1) / p.Bc;
+    const int ci = blockIdx.x % n_chunks, li = blockIdx.x / n_chunks;
+    const int b0 = ci * p.Bc, nb = min(p.Bc, p.B - b0);
+    const int R = p.max_repeat;
+    for (int v = lane; v <= R + 1; v += 64) hist[v] = 0;
+    __syncthreads();
+    int over = 0;
+    for (int t = lane; t < nb; t += 64) {
+        const long bh = (long)(b0 + t) * p.H + li;
+        const float* a = p.action + bh * 4;
+        const float x = a[0], z = a[1], th = a[2], len = a[3];
+        const float c = cosf(th), s = sinf(th);
+        const float xe = x - p.push_length * c, ze = z - p.push_length * s;            // plan_utils.py:13-15
+        float* dc = p.decoded + bh * 4;
+        dc[0] = x; dc[1] = z; dc[2] = xe; dc[3] = ze;
+        int rep = (int)len;                                                            // .to(int32): truncation (:16)
+        p.repeat[bh] = rep;
+        over = max(over, rep);
+        rep = min(max(rep, 0), R);
+        atomicAdd(&hist[rep], 1);                                                      // integer counts: order-free
+        const float dx = xe - x, dz = ze - z;                                          // forward_dynamics.py:48-50
+        for (int k = 0; k < p.M; ++k) {
+            float* xz = p.eef_xz + (bh * p.M + k) * 2;
+            float* dl = p.eef_delta + (bh * p.M + k) * 3;
+            xz[0] = k == 0 ? x : x + p.tool_off[k] * s;                                // :60-75
+            xz[1] = k == 0 ? z : z - p.tool_off[k] * c;
+            dl[0] = dx; dl[1] = 0.0f; dl[2] = dz;
+        }
+    }
+    for (int o = 1; o < 64; o <<= 1) over = max(over, __shfl_xor(over, o, 64));
+    if (lane == 0 && over > R) atomicMax(p.flags + 1, over);
+    __syncthreads();
+    if (lane == 0) {
+        // base[v] = candidates with a larger repeat (descending order); live[ai] = candidates with repeat >= ai
+        int acc = 0, sum_rep = 0, sum_live = 0;
+        int* live = p.live + ((long)ci * p.H + li) * (R + 2);
+        int* rows = p.rows + ((long)ci * p.H + li) * (R + 2);
+        live[R + 1] = 0; rows[R + 1] = 0;
+        for (int v = R; v >= 0; --v) {
+            base[v] = acc;
+            acc += hist[v];                                  // candidates with repeat >= v
+            // sorted: the live candidates are the first `acc` slots; unsorted: every slot while any candidate is live
+            live[v] = v == 0 ? nb : (p.sort ? acc : (acc > 0 ? nb : 0));
+            rows[v] = live[v] * p.N;
+            sum_rep += v * hist[v];
+            if (v >= 1) sum_live += live[v];
+        }
+        p.sums[((long)ci * p.H + li) * 2 + 0] = sum_rep;
+        p.sums[((long)ci * p.H + li) * 2 + 1] = sum_live;
+    }
+    __syncthreads();
+    for (int v = lane; v <= R; v += 64) hist[v] = 0;         // reused as the running fill of every bucket
+    __syncthreads();
+    int* seg = p.cand + (long)li * p.B + b0;
+    for (int t0 = 0; t0 < nb; t0 += 64) {                    // tiles in order, buckets filled in candidate order: stable
+        const int t = t0 + lane;
+        const bool on = t < nb;
+        const int rep = on ? min(max(p.repeat[(long)(b0 + t) * p.H + li], 0), R) : -1;
+        if (!p.sort) { if (on) seg[t] = b0 + t; continue; }
+        unsigned long long todo = __ballot(on);
+        while (todo) {
+            const int first = __ffsll((long long)todo) - 1;
+            const int v = __shfl(rep, first, 64);
+            const unsigned long long m = __ballot(on && rep == v);
+            if (on && rep == v) seg[base[v] + hist[v] + __popcll(m & ((1ull << lane) - 1ull))] = b0 + t;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == first) hist[v] += __popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~m;
+        }
+    }
+}
+hipError_t launch_roll_plan(const RollPlan& p, hipStream_t st) {
+    if (p.max_repeat > PLAN_MAXR) return hipErrorInvalidValue;
+    const int n_chunks = (p.B + p.Bc - 1) / p.Bc;
+    hipLaunchKernelGGL(k_roll_plan, dim3(n_chunks * p.H), dim3(64), 0, st, p);
     return hipGetLastError();
 }
 

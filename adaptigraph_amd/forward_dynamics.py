@@ -3,9 +3,16 @@
 src/planning/physics_param_optimizer.py:219).  Same signatures and return dicts as
 src/planning/forward_dynamics.py:12-205 and :209-399.
 
-Host side (this file): decode the action batch and lay out the tool keypoints with torch CPU ops, spelled as the
-reference spells them so every cos/sin/multiply rounds identically; everything after that - graph build, GNN
-forward, tool advance, history shift, capture - runs inside ONE C-ABI call with no host sync per step.
+Two ways in, same engine underneath:
+  * actions on the HOST (or option device_decode = 0): this file decodes the action batch and lays out the tool keypoints
+    with torch CPU ops, spelled as the reference spells them so every cos/sin/multiply rounds identically (bit-equal
+    'action_seqs' against a CPU reference); everything after that - graph build, GNN forward, tool advance, history shift,
+    capture - runs inside ONE C-ABI call (ag_rollout) with no host sync per step.
+  * actions RESIDENT ON THE GPU (what the planner's sampler produces) and a task config that bounds the push length
+    (task_config['action_upper_lim'], planning/*.yaml:28-29): ag_rollout_actions decodes them and plans the launches in a
+    device kernel - the host never reads an action, so nothing waits for the GPU between the sampler and the first rollout
+    kernel.  cos/sin are then the device's, as they would be for a reference running on a GPU: 'action_seqs' agrees with a
+    CPU decode to ~1e-7, not bit for bit.
 
 Deviations, both on paths that do not change any returned value:
   * candidates are advanced only while some candidate of their launch chunk is still live; the reference steps
@@ -87,12 +94,70 @@ def _run(model, dev, task, ppm_optimizer, physics_param, B, H, N_o, y_mode, stat
     return out
 
 
+def _repeat_bound(task):
+    """Upper bound of action_repeat = int(length) from the task config's action limits (planning/*.yaml:28-29), or None."""
+    lim = task.get("action_upper_lim") if hasattr(task, "get") else None
+    if lim is None:
+        return None
+    try:
+        return int(float(lim[3]))                       # yaml lists; a GPU tensor here would cost the sync this path avoids
+    except (TypeError, IndexError, ValueError):
+        return None
+
+
+def _run_device_actions(model, dev, task, ppm_optimizer, physics_param, action, state0, bound, sync, flags):
+    """ag_rollout_actions: decode + launch plan on the device (see module docstring)."""
+    if not isinstance(model, DynamicsPredictor):
+        raise TypeError("model must be an adaptigraph_amd.DynamicsPredictor")
+    eng = model.engine(dev)
+    B, H = action.shape[0], action.shape[1]
+    N_o, M = state0.shape[0], ppm_optimizer.eef_num
+    pts = task["pusher_points"]
+    if len(pts) != M or M not in (1, 5):
+        raise NotImplementedError("pusher not implemented")
+    grip = bool(task["gripper_enable"])
+    phys_val, phys_vec = _physics(ppm_optimizer, physics_param, N_o, dev)
+    p = _lib.AgRolloutParams(B, H, N_o, M, int(task["topk"]), int(bool(task["connect_tools_all"])), int(task["max_nR"]), 0,
+                             float(ppm_optimizer.adj_thresh), float(0.01 * task["sim_real_ratio"]) if grip else 0.0,
+                             int(grip), phys_val)
+    offs = (C.c_float * 8)(*([0.0] + [float(pts[k][1]) * task["sim_real_ratio"] for k in range(1, M)] + [0.0] * (8 - M)))
+    act = action.detach().to(dev, torch.float32).contiguous()
+    out = torch.empty((B, H, N_o, 3), device=dev, dtype=torch.float32)
+    decoded = torch.empty((B, H, 4), device=dev, dtype=torch.float32)
+    own_flags = flags is None
+    if own_flags:
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    assert flags.numel() >= 2 and flags.dtype == torch.int32
+    eng.check(eng.lib.ag_rollout_actions(eng.ctx, current_stream(dev), C.byref(p), ptr(state0), ptr(act),
+                                         float(task["push_length"]), offs, int(bound), ptr(phys_vec), ptr(out), ptr(decoded),
+                                         ptr(flags)))
+    if sync:
+        seen = flags[:2].tolist()                                                       # the one wait of the call
+        if seen[0] > int(task["max_nR"]):
+            raise Exception("Exceeds max dims")                                        # utils.py:63-65
+        if seen[1] > bound:
+            raise ValueError(f"an action's repeat count {seen[1]} exceeds the task config's action_upper_lim[3] = {bound}: "
+                             "the device-planned rollout launches every look-ahead step that many times (pass actions "
+                             "within the limits, or set option device_decode = 0)")
+    return out, decoded
+
+
 @torch.no_grad()
 def dynamics(state, action, model, device, ppm_optimizer, physics_param=None, _sync=True, _overflow_flag=None):
     """state (N_o,3), action (B,H,4) -> {'state_seqs': (B,H,N_o,3), 'action_seqs': (B,H,4)}"""
     task = ppm_optimizer.task_config
     dev = _require_gpu(device)
     B, H = action.shape[0], action.shape[1]
+    if action.is_cuda and isinstance(model, DynamicsPredictor):
+        mode = model.engine(dev).get_option("device_decode")
+        bound = _repeat_bound(task)
+        if mode == 1 and bound is None:
+            raise ValueError("option device_decode = 1 needs task_config['action_upper_lim'] (the bound of action_repeat)")
+        if mode != 0 and bound is not None:
+            state0 = state.detach().to(dev, torch.float32).contiguous()
+            out, decoded = _run_device_actions(model, dev, task, ppm_optimizer, physics_param, action, state0, bound,
+                                               _sync, _overflow_flag)
+            return {"state_seqs": out, "action_seqs": decoded.to(action.device)}
     action_cpu = action.detach().to("cpu", torch.float32)
     decoded, repeat = decode_action(action_cpu, push_length=task["push_length"])          # :23
     xz, delta = _tool_layout(decoded, action_cpu[:, :, 2], task)

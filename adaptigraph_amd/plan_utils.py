@@ -1,9 +1,11 @@
 """Action codec of the planner: replaces decode_action (reference src/planning/plan_utils.py:11-20).
 
 An action is (x, z, theta, length): a push that starts at (x, z), heads AGAINST the direction theta for `push_length`
-per repeat, and is applied int(length) times.  The decode runs with torch ops on the action's own device (the
-reference decodes there too, forward_dynamics.py:23), each product and difference in the reference's order so the
-fp32 bits agree: end = start - push_length * (cos theta, sin theta).
+per repeat, and is applied int(length) times: end = start - push_length * (cos theta, sin theta), each product and
+difference in the reference's order.  This function runs torch ops on whatever device `action` is on.  dynamics() calls it
+on the HOST copy of the actions (torch CPU cos/sin: bit-equal to a CPU reference) unless the actions are GPU-resident and
+the device-planned path applies - then the same arithmetic runs inside csrc/ag_graph.hip: k_roll_plan with the device's
+cos/sin (forward_dynamics.py docstring), and this function is not involved.
 """
 import torch
 

@@ -385,6 +385,9 @@ def main():
                                                "the other workgroup on its CU; achieved = algorithmic FLOPs resp. compulsory "
                                                "HBM bytes / HIP-event time; traffic = PMC FETCH_SIZE x2 + WRITE_SIZE per launch"},
             "kernel_ms_per_rollout_single_stream": {f: v[0] / prof_steps for f, v in fam_ms.items()},
+            # SHA-256 of the gathered per-candidate reward vector of the last timed step (fp32 bytes): sharded == unsharded
+            # bit for bit (tests/test_gpu_two_ranks.py compares the 2-rank line with the 1-rank line)
+            "reward_sha256": __import__("hashlib").sha256(costs.detach().cpu().numpy().tobytes()).hexdigest(),
         }
         # whole-rollout arithmetic rate: FLOPs the kernels execute per rollout step and candidate
         # (encoded edges x 140,100 + particles x (2 x 135,000 + 135,900) + 8 N^2 for the graph), and the reference

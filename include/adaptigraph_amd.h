@@ -115,7 +115,8 @@ int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
  *   "edge_block_min" [AG_EDGE_BLOCK_MIN]  rows per slice from which the 64-rows-per-wavefront schedule is used (-1 = built-in 256)
  *   "enc_persist"    [AG_ENC_PERSIST]     persistent workgroups of k_edge_enc (default 0 = one workgroup per tile)
  *   "stagger_us"     [AG_STAGGER_US]      start offset between the two workgroups of a CU in the propagate chains (default 0)
- *   "device_decode"  [AG_DEVICE_DECODE]   consumed by the Python shim: decode_action / tool layout on the device (default 0)
+ *   "device_decode"  [AG_DEVICE_DECODE]   consumed by the Python shim: dynamics() with GPU-resident actions goes through
+ *                                         ag_rollout_actions: -1 when task_config bounds the repeat (default), 0 never, 1 always
  * Unknown names return AG_ERR_INVALID. */
 int ag_ctx_set_option(ag_ctx* ctx, const char* name, int32_t value);
 int ag_ctx_get_option(ag_ctx* ctx, const char* name, int32_t* out_value);
@@ -203,6 +204,24 @@ int ag_rollout_async(ag_ctx* ctx, void* stream, const ag_rollout_params* p, cons
                      const uint8_t* d_obj_mask, const float* d_eef_xz, const float* d_eef_delta,
                      const int32_t* h_repeat, const float* d_phys_vec, float* d_state_seqs,
                      int32_t* d_overflow_flag);
+
+/* dynamics() for actions that are RESIDENT ON THE GPU (the planner samples them there): decode_action
+ * (src/planning/plan_utils.py:11-20), the tool-keypoint layout (forward_dynamics.py:42-75) and the repeat-aware launch plan
+ * all run in one device kernel; the host never reads an action, so nothing between the caller's sampling kernel and the
+ * first rollout kernel waits for the GPU.  Enqueue only (like ag_rollout_async).
+ *   d_action        (B,H,4) raw [x, z, theta, length]
+ *   push_length     task_config push_length;  h_tool_offsets (M,) HOST: pusher_points[k][1] * sim_real_ratio (entry 0 unused;
+ *                   may be NULL when M == 1)
+ *   max_repeat      upper bound of action_repeat = int(length) the caller guarantees (e.g. its action_upper_lim[3]); every
+ *                   look-ahead step is launched max_repeat times, steps past a chunk's own maximum find no live slot and exit
+ *   d_action_seqs   (B,H,4) output: decoded actions [x_start, z_start, x_end, z_end] (the reference's 'action_seqs')
+ *   d_flags         (>= 2 int32, device, caller-zeroed): [0] max edge count seen if it exceeded max_nR (as ag_rollout_async),
+ *                   [1] largest action_repeat seen if it exceeded max_repeat (the results of such a candidate are invalid)
+ * cos / sin are the device's: decoded values agree with a host decode to an ulp or two (a CUDA-resident reference would
+ * use device transcendental functions too); everything downstream is the same arithmetic as ag_rollout. y_mode must be 0. */
+int ag_rollout_actions(ag_ctx* ctx, void* stream, const ag_rollout_params* p, const float* d_state0, const float* d_action,
+                       float push_length, const float* h_tool_offsets, int32_t max_repeat, const float* d_phys_vec,
+                       float* d_state_seqs, float* d_action_seqs, int32_t* d_flags);
 
 /* ---- Per-candidate cost functions: SURVEY §8(f) rank 1 (reference src/planning/losses.py, src/planning/plan.py:27-59) ---- */
 

@@ -597,6 +597,7 @@ _, m = _model(ag, O, "cloth", 29, dev)                                  # contex
 good = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"].clone()
 os.environ["AG_TEST_FAIL_AT_CHUNK"] = "1"                              # the hook is read when a context is created
 _, bad = _model(ag, O, "cloth", 29, dev)
+bad.engine(dev)                                                         # (the context is created on first use)
 del os.environ["AG_TEST_FAIL_AT_CHUNK"]
 try:
     ag.dynamics(s0, a, bad, dev, _ppm(task, "cloth"))
@@ -895,3 +896,108 @@ def test_two_contexts_in_one_process_keep_their_own_options(ag, O, dev):
     assert n1 == n2 == int(reps.sum()) and x2 == n2 and x1 == 40 * int(reps.max())
     with pytest.raises(AssertionError, match="unknown option"):
         e1.set_option("no_such_switch", 1)
+
+
+def test_shipped_planner_configuration_chunked_equals_loop_at_size(ag, O, dev):
+    """The shipped planner workload at its own size (planning/rope.yaml: n_sample_chunk 500, n_look_ahead 1, push length
+    U[5,15) -> action_repeat 5..14, 200+1 particles; tools/bench_planner.py times 40 such chunks): two chunks through the
+    reference's host loop (plan.py:241-247) and through trajectory_optimization_chunked - bit-identical, repeat-sorted
+    launch order included (the 1000-candidate call cuts its launch chunks differently from the 500-candidate calls) - and
+    the winner against the oracle."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_planner as BP
+    rng = np.random.default_rng(0)
+    planner, m, s0, lo, hi, cloud, task = BP.make_planner("rope", 500, rng)
+    torch.manual_seed(0)
+    act_seq = torch.rand((1, 4), device=dev) * (hi - lo) + lo
+    torch.manual_seed(1)
+    loop = BP.loop_call(planner, s0, act_seq, 2)
+    gen = torch.cuda.get_rng_state(dev)
+    torch.manual_seed(1)
+    fused = planner.trajectory_optimization_chunked(s0, act_seq, 2)
+    assert torch.equal(torch.cuda.get_rng_state(dev), gen)
+    assert torch.equal(fused["act_seq"], loop["act_seq"])
+    assert torch.equal(fused["best_model_output"]["state_seqs"], loop["best_model_output"]["state_seqs"])
+    assert torch.equal(fused["best_eval_output"]["reward_seqs"], loop["best_eval_output"]["reward_seqs"])
+    # the 1000-candidate rollout ran exactly sum(action_repeat) candidate-forwards
+    torch.manual_seed(1)
+    a = torch.cat([planner.sample_action_sequences(act_seq, iter_index=0) for _ in range(2)])
+    planner.model_rollout(s0, a)
+    ex, need = m.engine(dev).rollout_counts()
+    assert ex == need == int(a[:, 0, 3].to(torch.int32).sum())
+    assert 5 <= int(a[:, 0, 3].min()) and int(a[:, 0, 3].max()) <= 14
+    W = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    want = O.dynamics(W, 3, cloud, loop["act_seq"].cpu().numpy()[None], {k: v for k, v in task.items()})["state_seqs"]
+    assert np.abs(loop["best_model_output"]["state_seqs"].cpu().numpy() - want).max() <= POS_TOL
+
+
+# ------------------------------------------------------------------------------------------------- device-planned rollouts
+@pytest.mark.parametrize("name,material", [("dyn_rope", "rope"), ("dyn_granular", "granular"), ("dyn_cloth", "cloth")])
+def test_device_decoded_actions_vs_reference_golden(ag, dev, name, material):
+    """GPU-resident actions + a task config that bounds the push length take ag_rollout_actions: decode_action, the tool
+    keypoints (1-point / 5-point pusher, gripper) and the launch plan run in a device kernel.  Against the reference's
+    goldens: decoded actions to 1e-6 (device cos/sin), states to 1e-5; the host-decode path stays selectable and bit-equal."""
+    from helpers import load_golden, task_of
+    from test_gpu_parity import _model as _gmodel
+    g = load_golden(name)
+    task = task_of(g)
+    m = _gmodel(ag, g, material, dev)
+    s0, a = torch.from_numpy(g["state0"]).to(dev), torch.from_numpy(g["action"]).to(dev)
+    host = ag.dynamics(s0, a, m, dev, _ppm(task, material))
+    assert torch.equal(host["action_seqs"].cpu(), torch.from_numpy(g["action_seqs"]))
+    tdev = dict(task, action_upper_lim=[0.0, 4.5, 3.14, 4.0], action_lower_lim=[-4.5, -2.5, -3.14, 2.0])
+    eng = m.engine(dev)
+    out = ag.dynamics(s0, a, m, dev, _ppm(tdev, material))
+    assert eng.rollout_counts()[0] == eng.rollout_counts()[1] == int(g["action"][..., 3].astype(np.int32).sum())
+    assert out["action_seqs"].is_cuda
+    assert float((out["action_seqs"].cpu() - torch.from_numpy(g["action_seqs"])).abs().max()) <= 1e-6
+    assert np.abs(out["state_seqs"].cpu().numpy() - g["state_seqs"]).max() <= POS_TOL
+    with eng.options(device_decode=0):                                  # same task config, host decode: bit-equal again
+        again = ag.dynamics(s0, a, m, dev, _ppm(tdev, material))
+    assert torch.equal(again["action_seqs"], host["action_seqs"]) and torch.equal(again["state_seqs"], host["state_seqs"])
+    cpu_actions = ag.dynamics(s0, a.cpu(), m, dev, _ppm(tdev, material))   # host-resident actions never take the device path
+    assert torch.equal(cpu_actions["state_seqs"], host["state_seqs"])
+
+
+def test_device_planned_rollout_is_invariant_to_order_chunks_and_streams(ag, O, dev):
+    """ag_rollout_actions with mixed repeats 2..9 (incl. 0): the device's repeat-sorted plan vs the unsorted one (every slot
+    stepped while any is live), one / two streams, odd chunk sizes - identical bits; executed candidate-forwards = sum of
+    repeats; a repeat beyond the task config's bound is reported, not silently truncated."""
+    rng = np.random.default_rng(103)
+    task = _task("cloth", max_nR=40000, action_lower_lim=[-4.5, -2.5, -3.14, 2.0], action_upper_lim=[0.0, 4.5, 3.14, 10.0])
+    W, m = _model(ag, O, "cloth", 103, dev)
+    cloud = _grid(30, 0.3, 0.02, rng)
+    B, H = 150, 2
+    reps = rng.integers(2, 10, (B, H))
+    reps[5, 1] = 0
+    a_np = _actions(cloud, B, H, reps, rng, spread=0.8)
+    a_np[5, 1, 3] = 0.25
+    s0, a = torch.from_numpy(cloud).to(dev), torch.from_numpy(a_np).to(dev)
+    ppm = _ppm(task, "cloth")
+    eng = m.engine(dev)
+    outs = []
+    for streams, chunk, sort in ((1, 0, 1), (2, 0, 1), (1, 37, 1), (2, 41, 0), (1, 0, 0)):
+        with eng.options(streams=streams, repeat_sort=sort):
+            eng.set_chunk(chunk)
+            try:
+                o = ag.dynamics(s0, a, m, dev, ppm)
+                ex, need = eng.rollout_counts()
+            finally:
+                eng.set_chunk(0)
+        assert need == int(reps.sum()) and (ex == need if sort else ex > need), (streams, chunk, sort, ex, need)
+        outs.append(o)
+    for o in outs[1:]:
+        assert torch.equal(o["state_seqs"], outs[0]["state_seqs"]) and torch.equal(o["action_seqs"], outs[0]["action_seqs"])
+    assert float(outs[0]["state_seqs"][5, 1].abs().max()) == 0.0        # repeat 0: the slot stays zero
+    with eng.options(device_decode=0):
+        host = ag.dynamics(s0, a, m, dev, ppm)
+    assert float((host["action_seqs"] - outs[0]["action_seqs"]).abs().max()) <= 1e-6
+    err = (host["state_seqs"] - outs[0]["state_seqs"]).abs().reshape(B, -1).max(1).values
+    assert int((err <= POS_TOL).sum()) >= B - 3, err.topk(5)            # (1e-7 tool offsets may pass a near-tie in a long rollout)
+    too_long = a.clone()
+    too_long[7, 0, 3] = 12.5
+    with pytest.raises(ValueError, match="action_upper_lim"):
+        ag.dynamics(s0, too_long, m, dev, ppm)
+    ok = ag.dynamics(s0, a, m, dev, ppm)                                 # the context is still usable
+    assert torch.equal(ok["state_seqs"], outs[0]["state_seqs"])
