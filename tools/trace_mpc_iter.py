@@ -20,7 +20,7 @@ def report(d):
     by_corr = {r["Correlation_Id"]: r for r in api}
     samples = [k for k in ker if "k_mppi_sample" in k["Kernel_Name"]]
     res = []
-    for s in samples[-4:]:                                   # the last iterations (warm)
+    for s in samples:
         nxt = next((k for k in ker if int(k["Start_Timestamp"]) > int(s["Start_Timestamp"]) and
                     ("k_roll_plan" in k["Kernel_Name"] or "k_roll_init" in k["Kernel_Name"])), None)
         if nxt is None:
@@ -35,7 +35,9 @@ def report(d):
                     (int(a1["Start_Timestamp"]) - int(a0["End_Timestamp"])) / 1e3, "gpu_idle_us_between_kernels":
                     (int(nxt["Start_Timestamp"]) - int(s["End_Timestamp"])) / 1e3, "hip_calls_between": between,
                     "blocking_calls_between": blocking})
-    print(json.dumps(res, indent=1))
+    # the last two (warm) iterations of each path
+    out = [r for kind in ("k_roll_plan", "k_roll_init") for r in [x for x in res if kind in x["first_rollout_kernel"]][-2:]]
+    print(json.dumps(out, indent=1))
 
 
 def main():
