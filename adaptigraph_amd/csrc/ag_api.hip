@@ -297,7 +297,7 @@ size_t work_bytes(int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices
     size_t bytes = 16 * 256;
     bytes += rows * (NODE_IN + F15_PITCH + (own_group ? n_inst : 0)) * 4 + 6 * rows * NFP * 4 + ((size_t)Bc * c_cap + 256) * NFP * 4;
     if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 3) * 4 + 3 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
-    if (roll) bytes += rows * 4 + 1024 + (size_t)Bc * N_HIS * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
+    if (roll) bytes += rows * 4 + 1024 + (size_t)Bc * N_HIS_MAX * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
                        (size_t)cls_rows(N_o, N - N_o, Bc) * (NODE_IN + 4 * NFP) * 4;
     return bytes + 64 * 256;
 }
@@ -333,7 +333,7 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
     if (roll) {
         w.rowlist = s.take<int>(rows);
         w.n_rows = s.take<int>(64);
-        w.r.hist = s.take<float>((size_t)Bc * N_HIS * N * 3);
+        w.r.hist = s.take<float>((size_t)Bc * N_HIS_MAX * N * 3);   // (Bc, n_his, N, 3) with the model's n_his (4 or 5)
         w.r.pred = s.take<float>((size_t)Bc * N_o * 3);
         w.r.motion = s.take<float>((size_t)Bc * N_o * 3);
         w.r.mask = s.take<uint8_t>(rows);
@@ -465,7 +465,7 @@ int ag_ctx_create(int32_t device_id, const ag_dims* dims, ag_ctx** out) {
     const bool his_ok = (dims->n_his == 4 || dims->n_his == N_HIS_MAX) && dims->rel_dim == 5 + 3 * dims->n_his;
     if (dims->nf != NF || !his_ok || dims->in_dim != IN_DIM)
         return fail(c, AG_ERR_UNSUPPORTED, "kernels are built for nf=150, in_dim=6 and n_his=4 (rel_dim 17) or n_his=5 "
-                    "(rel_dim 20, forward only) - got nf %d, n_his %d, in_dim %d, rel_dim %d", dims->nf, dims->n_his, dims->in_dim, dims->rel_dim);
+                    "(rel_dim 20) - got nf %d, n_his %d, in_dim %d, rel_dim %d", dims->nf, dims->n_his, dims->in_dim, dims->rel_dim);
     if (dims->pstep < 1) return fail(c, AG_ERR_INVALID, "pstep must be >= 1");
     HIPCHK(c, hipSetDevice(device_id));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_w), (size_t)WeightLayout::TOTAL * 4));
@@ -776,8 +776,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         return fail(c, AG_ERR_INVALID, "ag_rollout: bad sizes B=%d H=%d N_o=%d M=%d max_nR=%d", p->B, p->H, p->N_o, p->M, p->max_nR);
     if (p->y_mode != 0 && p->y_mode != 1) return fail(c, AG_ERR_INVALID, "y_mode must be 0 or 1");
     if (p->y_mode == 1 && p->H != 1) return fail(c, AG_ERR_INVALID, "masked rollout has a single look-ahead step");
-    if (c->dims.n_his != N_HIS)
-        return fail(c, AG_ERR_UNSUPPORTED, "the rollout driver is built for n_his=4 (every planner task config); this model has n_his=%d", c->dims.n_his);
+    const int n_his = c->dims.n_his;                          // 4 (every planner task config) or 5 (softbody.yaml:29)
     const int N = p->N_o + p->M;
     int rc = check_topk(c, N, p->topk);
     if (rc) return rc;
@@ -932,7 +931,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         hipStream_t cs = streams[ci % ns];
         c->prof_stream = cs;
         GraphBufs g = w.g;
-        g.B = nb; g.n_p = p->N_o;
+        g.B = nb; g.n_p = p->N_o; g.n_his = n_his;
         g.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
         if (dedupe) {
             g.c_self = c->d_cself; g.ns_edge = w.ns_edge; g.n_ns = w.n_ns;
@@ -945,7 +944,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         ra.state0 = d_state0; ra.state0_batched = p->y_mode == 1; ra.obj_mask = d_obj_mask;
         ra.eef_xz = d_eef_xz; ra.eef_delta = d_eef_delta; ra.repeat = dev_plan ? pl_repeat : c->d_repeat; ra.state_seqs = d_state_seqs;
         EdgeArgs ea{};
-        ea.pos = w.r.hist + (size_t)(N_HIS - 1) * N * 3; ea.pos_bstride = (long)N_HIS * N * 3;
+        ea.pos = w.r.hist + (size_t)(n_his - 1) * N * 3; ea.pos_bstride = (long)n_his * N * 3;   // the newest frame
         ea.mask = w.r.mask; ea.tool = w.r.tool; ea.thr_vec = nullptr; ea.thr = p->adj_thresh;
         ea.B = nb; ea.N = N; ea.topk = p->topk; ea.cta = p->connect_tools_all ? 1 : 0; ea.edge_cap = edge_cap;
         ea.slices = slices; ea.ell = w.ell; ea.deg = w.deg; ea.slice_tot = w.slice_tot; ea.cta_flag = w.cta_flag;

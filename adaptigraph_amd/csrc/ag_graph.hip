@@ -112,7 +112,9 @@ __device__ float tool_y(const float* src, const uint8_t* om, int N_o, int y_mode
 // Start of look-ahead step li (forward_dynamics.py:37-123 / 225-317): object cloud = start state (li == 0) or the
 // captured prediction of step li-1; all n_his frames equal; tool keypoints from the decoded action; attrs, masks,
 // p_instance, physics parameter, action rows.
+template <int NH>
 __global__ __launch_bounds__(RT) void k_roll_init(RollDev d) {
+    constexpr int FP = NH == 5 ? F15_PITCH : F12;           // feature-row pitch: 3 * NH floats (+ pad for NH = 5)
     __shared__ float red[RT];
     __shared__ int redi[RT];
     const RollArgs& a = d.a;
@@ -147,13 +149,13 @@ __global__ __launch_bounds__(RT) void k_roll_init(RollDev d) {
         }
         const long row = (long)b * N + i;
 #pragma unroll
-        for (int h = 0; h < N_HIS; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) d.hist[(((long)b * N_HIS + h) * N + i) * 3 + c] = p[c];
-        float* f = d.feat12 + row * F12;
+            for (int c = 0; c < 3; ++c) d.hist[(((long)b * NH + h) * N + i) * 3 + c] = p[c];
+        float* f = d.feat12 + row * FP;
 #pragma unroll
-        for (int c = 0; c < 9; ++c) f[c] = 0.0f;             // identical frames: residuals are exactly 0
-        f[9] = p[0]; f[10] = p[1]; f[11] = p[2];
+        for (int c = 0; c < FP; ++c) f[c] = 0.0f;            // identical frames: residuals are exactly 0 (and the row's pad)
+        f[3 * (NH - 1)] = p[0]; f[3 * (NH - 1) + 1] = p[1]; f[3 * (NH - 1) + 2] = p[2];
         const bool ov = is_tool ? false : (om ? om[i] != 0 : true);
         float* n = d.node_in + row * NODE_IN;
         n[0] = ov ? 1.0f : 0.0f;                             // attrs[:, :nobj, 0] (:92 / :287)
@@ -182,7 +184,9 @@ __global__ __launch_bounds__(RT) void k_roll_init(RollDev d) {
 
 // After forward number ai of look-ahead step li (forward_dynamics.py:160-176 / 356-372): capture, tool advance,
 // history shift, history features for the next forward.
+template <int NH>
 __global__ __launch_bounds__(RT) void k_roll_update(RollDev d) {
+    constexpr int FP = NH == 5 ? F15_PITCH : F12;
     __shared__ float red[RT];
     __shared__ int redi[RT];
     const RollArgs& a = d.a;
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(RT) void k_roll_update(RollDev d) {
             if (om[i]) continue;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float cur = d.hist[(((long)b * N_HIS + (N_HIS - 1)) * N + i) * 3 + c];
+                const float cur = d.hist[(((long)b * NH + (NH - 1)) * N + i) * 3 + c];
                 pred[3 * i + c] = cur + fminf(fmaxf(d.motion_inv[3 * i + c], -d.clamp), d.clamp);
             }
         }
@@ -213,37 +217,37 @@ __global__ __launch_bounds__(RT) void k_roll_update(RollDev d) {
     if (a.grip_on) y = y + a.grip;                           // :167-168
     for (int i = tid; i < N; i += RT) {
         const long row = (long)b * N + i;
-        float h[N_HIS][3];
+        float h[NH][3];
 #pragma unroll
-        for (int k = 0; k < N_HIS; ++k)
+        for (int k = 0; k < NH; ++k)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) h[k][c] = d.hist[(((long)b * N_HIS + k) * N + i) * 3 + c];
+            for (int c = 0; c < 3; ++c) h[k][c] = d.hist[(((long)b * NH + k) * N + i) * 3 + c];
         float nw[3];
         if (i < a.N_o) {
             nw[0] = pred[3 * i]; nw[1] = pred[3 * i + 1]; nw[2] = pred[3 * i + 2];     // :170
         } else {
             const float* act = d.node_in + row * NODE_IN + 3;
-            nw[0] = h[N_HIS - 1][0] + act[0];                                          // :164
+            nw[0] = h[NH - 1][0] + act[0];                                          // :164
             nw[1] = y;                                                                 // :166
-            nw[2] = h[N_HIS - 1][2] + act[2];
+            nw[2] = h[NH - 1][2] + act[2];
         }
 #pragma unroll
-        for (int k = 0; k < N_HIS - 1; ++k)
+        for (int k = 0; k < NH - 1; ++k)
 #pragma unroll
             for (int c = 0; c < 3; ++c) h[k][c] = h[k + 1][c];                         // :176
 #pragma unroll
-        for (int c = 0; c < 3; ++c) h[N_HIS - 1][c] = nw[c];
+        for (int c = 0; c < 3; ++c) h[NH - 1][c] = nw[c];
 #pragma unroll
-        for (int k = 0; k < N_HIS; ++k)
+        for (int k = 0; k < NH; ++k)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) d.hist[(((long)b * N_HIS + k) * N + i) * 3 + c] = h[k][c];
-        float* f = d.feat12 + row * F12;
+            for (int c = 0; c < 3; ++c) d.hist[(((long)b * NH + k) * N + i) * 3 + c] = h[k][c];
+        float* f = d.feat12 + row * FP;
 #pragma unroll
-        for (int k = 0; k < N_HIS - 1; ++k)
+        for (int k = 0; k < NH - 1; ++k)
 #pragma unroll
             for (int c = 0; c < 3; ++c) f[3 * k + c] = h[k + 1][c] - h[k][c];          // model.py:156
 #pragma unroll
-        for (int c = 0; c < 3; ++c) f[9 + c] = h[N_HIS - 1][c];
+        for (int c = 0; c < 3; ++c) f[3 * (NH - 1) + c] = h[NH - 1][c];
     }
 }
 
@@ -390,12 +394,15 @@ static RollDev to_dev(const RollArgs& a, const RollBufs& r, const GraphBufs& g) 
     d.c_node_in = g.cls_on ? g.c_node_in : nullptr; d.write_obj_cls = a.write_obj_cls;
     return d;
 }
+// g.n_his: history frames of the model (4: every planner task config; 5: config/dynamics/softbody.yaml:29)
 hipError_t launch_roll_init(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st) {
-    hipLaunchKernelGGL(k_roll_init, dim3(a.B), dim3(RT), 0, st, to_dev(a, r, g));
+    if (g.n_his == 5) hipLaunchKernelGGL(k_roll_init<5>, dim3(a.B), dim3(RT), 0, st, to_dev(a, r, g));
+    else hipLaunchKernelGGL(k_roll_init<4>, dim3(a.B), dim3(RT), 0, st, to_dev(a, r, g));
     return hipGetLastError();
 }
 hipError_t launch_roll_update(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st) {
-    hipLaunchKernelGGL(k_roll_update, dim3(a.B), dim3(RT), 0, st, to_dev(a, r, g));
+    if (g.n_his == 5) hipLaunchKernelGGL(k_roll_update<5>, dim3(a.B), dim3(RT), 0, st, to_dev(a, r, g));
+    else hipLaunchKernelGGL(k_roll_update<4>, dim3(a.B), dim3(RT), 0, st, to_dev(a, r, g));
     return hipGetLastError();
 }
 

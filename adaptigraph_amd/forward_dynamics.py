@@ -75,6 +75,7 @@ def _run(model, dev, task, ppm_optimizer, physics_param, B, H, N_o, y_mode, stat
     eng = model.engine(dev)
     M = ppm_optimizer.eef_num
     assert xz.shape[2] == M
+    assert int(task["n_his"]) == model.n_his, "task_config['n_his'] (forward_dynamics.py:16) must be the model's n_his"
     grip = bool(task["gripper_enable"])
     phys_val, phys_vec = _physics(ppm_optimizer, physics_param, N_o, dev)
     adj = ppm_optimizer.adj_thresh
@@ -110,6 +111,7 @@ def _run_device_actions(model, dev, task, ppm_optimizer, physics_param, action, 
     if not isinstance(model, DynamicsPredictor):
         raise TypeError("model must be an adaptigraph_amd.DynamicsPredictor")
     eng = model.engine(dev)
+    assert int(task["n_his"]) == model.n_his, "task_config['n_his'] (forward_dynamics.py:16) must be the model's n_his"
     B, H = action.shape[0], action.shape[1]
     N_o, M = state0.shape[0], ppm_optimizer.eef_num
     pts = task["pusher_points"]

@@ -59,7 +59,7 @@ class DynamicsPredictor(nn.Module):
                 not (self.nf_particle == self.nf_relation == self.nf_effect == 150):
             raise NotImplementedError(
                 "the HIP kernels are built for input_dim 6, nf 150 and n_his 4 (rel_input_dim 17: config/dynamics/"
-                "{rope,granular,cloth,...}.yaml) or n_his 5 (rel_input_dim 20: softbody.yaml, forward() only) - got "
+                "{rope,granular,cloth,...}.yaml) or n_his 5 (rel_input_dim 20: softbody.yaml) - got "
                 f"{input_dim}, {self.nf_effect}, {self.n_his}, {rel_input_dim}")
         self.input_dim, self.rel_input_dim = input_dim, rel_input_dim
 

@@ -60,10 +60,13 @@ def cloth_cloud(side, rng):
     return (p + rng.normal(0, 0.02, p.shape)).astype(np.float32)
 
 
-def make_task(max_nR):
-    return dict(adj_thresh=0.75, topk=5, connect_tools_all=True, sim_real_ratio=10, push_length=0.1,
-                gripper_enable=True, max_n=1, max_nR=max_nR, n_his=4, eef_num=1, material="cloth",
-                pusher_points=[[0.0, 0.0, 0.170]], material_dims={"cloth": 1}, material_indices={"cloth": 0})
+def make_task(max_nR, limits=True):
+    t = dict(adj_thresh=0.75, topk=5, connect_tools_all=True, sim_real_ratio=10, push_length=0.1,
+             gripper_enable=True, max_n=1, max_nR=max_nR, n_his=4, eef_num=1, material="cloth",
+             pusher_points=[[0.0, 0.0, 0.170]], material_dims={"cloth": 1}, material_indices={"cloth": 0})
+    if limits:   # planning/cloth.yaml:28-29.  With them in the task config GPU-resident actions take the device-planned path
+        t.update(action_lower_lim=[-4.5, -2.5, -3.14, 2.0], action_upper_lim=[0.0, 4.5, 3.14, 10.0])   # (ag_rollout_actions)
+    return t
 
 
 def model_cfg():
@@ -146,6 +149,8 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel family (adds overhead)")
     ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-bf16x3", action="store_true", help="skip the secondary bf16x3-mode measurement")
+    ap.add_argument("--host-decode", action="store_true", help="decode the actions on the host (ag_rollout) instead of the "
+                    "device-planned path the planner's GPU-resident samples take (ag_rollout_actions)")
     ap.add_argument("--no-mpc-iter", action="store_true", help="skip the ms/MPC-iteration leg (profiling runs: its B=1 "
                     "best-candidate rollouts would dilute per-kernel averages)")
     args = ap.parse_args()
@@ -175,7 +180,7 @@ def main():
     cloud = cloth_cloud(args.side, rng)
     N_o = cloud.shape[0]
     B, H, R = args.candidates, args.lookahead, args.repeat
-    task = make_task(max_nR=int(1.2 * 6 * (N_o + 1)) + 64)
+    task = make_task(max_nR=int(1.2 * 6 * (N_o + 1)) + 64, limits=not args.host_decode and args.repeat <= 10)
     Wt = random_weights(0)
     model = ag.DynamicsPredictor(*model_cfg(), dev)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in Wt.items()})
@@ -234,6 +239,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     assert int(flag[0].item()) <= task["max_nR"], "a graph exceeded max_nR during the bench"
+    assert int(flag[1].item()) <= args.repeat, "an action_repeat exceeded the task config's bound during the bench"
     assert torch.isfinite(costs).all()
     # candidates of the timed batch that the CPU leg re-computes with the oracle: first, last and evenly spaced ones
     # (every launch chunk of both streams is hit); their GPU results come from the LAST TIMED step
@@ -339,7 +345,7 @@ def main():
                 return None
             return tj["hbm_bytes_per_launch"] if abs(tj[key] - want) <= 0.01 * want else None
 
-        traffic = pmc_traffic("r02_traffic_k_edge_enc.json", "edges_per_launch", edges_per_launch)
+        traffic = pmc_traffic("r03_traffic_k_edge_enc.json", "edges_per_launch", edges_per_launch)
         achieved = FLOP_PER_EDGE * edges_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         # second-largest family: the propagate chain with the message passing fused into it (k_node_prop<false>, two
         # launches per rollout step).  It is bounded by BOTH resources, so both fractions are reported: the matrix work
@@ -354,7 +360,7 @@ def main():
         np_avg_ms = ms_np / max(1, n_np)
         np_tflops = np_flop_launch / (np_avg_ms * 1e-3) / 1e12 if np_avg_ms > 0 else 0.0
         np_gbs = np_bytes_launch / (np_avg_ms * 1e-3) / 1e9 if np_avg_ms > 0 else 0.0
-        np_traffic = pmc_traffic("r02_traffic_k_node_prop.json", "candidates_per_launch", cand_per_launch)
+        np_traffic = pmc_traffic("r03_traffic_k_node_prop.json", "candidates_per_launch", cand_per_launch)
         line = {
             "metric": "rollout-steps/sec", "value": total_steps * args.steps / dt, "unit": "rollout-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -363,7 +369,9 @@ def main():
                                    "repeat 10) x 2025+1 particles, radius graph rebuilt every step",
                        "candidates": B, "horizon": H * R, "particles": N_o + 1, "edges_per_graph": E, "edges_encoded_per_graph": E_enc,
                        "parallelism": f"candidates sharded over {world} GPU(s), all-gather of costs",
-                       "ms_per_mpc_rollout": dt / args.steps * 1e3, "ms_per_mpc_iter": ms_mpc},
+                       "ms_per_mpc_rollout": dt / args.steps * 1e3, "ms_per_mpc_iter": ms_mpc,
+                       "action_path": "host decode (ag_rollout)" if "action_upper_lim" not in task else
+                                      "device-planned (ag_rollout_actions: decode + launch plan on the GPU)"},
             "roofline": {"bound": "mfma", "kernel": "k_edge_enc", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches": int(n_edge),

@@ -48,11 +48,13 @@ typedef struct ag_ctx ag_ctx;
 /* Model dimensions = what DynamicsPredictor.__init__ derives from model_config
  * (src/dynamics/gnn/model.py:78-123).  Every shipped config has nf=150, in_dim=6 (attr 2 + physics 1 + action 3) and
  * rel_dim = 2*attr 2 + group 1 + 3*n_his: 17 with n_his=4 (rope, granular, cloth, ... and every planner task config),
- * 20 with n_his=5 (config/dynamics/softbody.yaml:29).  n_his=5 is served by ag_forward only (the eval-rollout path's
- * model(**graph), rollout.py:112); ag_rollout and the bf16x3 arithmetic return AG_ERR_UNSUPPORTED for it. */
+ * 20 with n_his=5 (config/dynamics/softbody.yaml:29).  Both are served by ag_forward and by the rollout driver (dynamics()
+ * takes n_his from the task config it is handed, forward_dynamics.py:16); the bf16x3 arithmetic and the latency-mode chains
+ * are built for n_his=4 (ag_ctx_set_precision returns AG_ERR_UNSUPPORTED for an n_his=5 model; small n_his=5 launches
+ * simply run the throughput kernels). */
 typedef struct ag_dims {
     int32_t nf;            /* nf_particle == nf_relation == nf_effect; kernels are built for 150 */
-    int32_t n_his;         /* history frames: 4, or 5 (forward only)                             */
+    int32_t n_his;         /* history frames: 4 or 5                                             */
     int32_t pstep;         /* message-passing rounds (3; softbody.yaml uses 4)                   */
     int32_t in_dim;        /* particle-encoder input width, must be 6                            */
     int32_t rel_dim;       /* relation-encoder input width, must be 5 + 3*n_his                  */

@@ -433,7 +433,7 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5", "--planner", "--fullsize"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5", "--planner", "--fullsize", "--nhis5-rollout"} & set(sys.argv)):
     main()
 
 # dynamics_masked for the other two materials: gripper offset + connect_tools_all (cloth) and the 5-point pusher
@@ -973,3 +973,44 @@ def gen_fullsize_all():
 
 if __name__ == "__main__" and "--fullsize" in sys.argv:
     gen_fullsize_all()
+
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# dynamics() with the softbody model variant (n_his = 5, pstep = 4; r03).  No planning config ships for it
+# (config/planning/ holds rope, granular, cloth), but dynamics() takes n_his from whatever task config it is given
+# (forward_dynamics.py:16): the rope task with n_his = 5 and the softbody model.
+def gen_nhis5_rollout(name):
+    refs = import_reference()
+    DynamicsPredictor, _, dynamics, _ = refs
+    rng = np.random.default_rng(18)
+    with open(f"{REF}/config/dynamics/softbody.yaml") as f:
+        dyn = yaml.safe_load(f)
+    _, task = load_cfg("rope")
+    task = dict(task)
+    task.update(n_his=5, max_nR=4000, material="softbody", material_dims={"softbody": 1}, material_indices={"softbody": 0})
+    model = make_model(DynamicsPredictor, dyn, 18)
+    ppm = make_ppm(task, "softbody")
+    cloud = rope_cloud(150, rng)
+    action = torch.from_numpy(actions_near(cloud, 3, 2, rng, 2.1, 4.9))
+    rec = Recorder(model)
+    np.random.seed(18)
+    out = quiet(dynamics, torch.from_numpy(cloud), action, model, torch.device("cpu"), ppm)
+    N = cloud.shape[0] + 1
+    mask = torch.ones((3, N), dtype=torch.bool)
+    tool = torch.zeros((3, N), dtype=torch.bool)
+    tool[:, -1] = True
+    for st in rec.steps:
+        assert_no_topk_boundary_tie(torch.from_numpy(st["state_last"]), mask, tool, task["adj_thresh"], task["topk"])
+    store = weights_npz(model)
+    store.update(state0=cloud, action=action.numpy(), state_seqs=out["state_seqs"].numpy(), action_seqs=out["action_seqs"].numpy(),
+                 pstep=np.int32(dyn["model_config"]["pstep"]), n_his=np.int32(5))
+    store["task_json"] = np.frombuffer(json.dumps(task_scalars(task)).encode(), dtype=np.uint8)
+    rec.dump(store)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: steps={len(rec.steps)} -> {os.path.getsize(path)/1e6:.2f} MB")
+
+
+if __name__ == "__main__" and "--nhis5-rollout" in sys.argv:
+    gen_nhis5_rollout("dyn_softbody_nhis5")

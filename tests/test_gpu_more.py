@@ -1001,3 +1001,37 @@ def test_device_planned_rollout_is_invariant_to_order_chunks_and_streams(ag, O, 
         ag.dynamics(s0, too_long, m, dev, ppm)
     ok = ag.dynamics(s0, a, m, dev, ppm)                                 # the context is still usable
     assert torch.equal(ok["state_seqs"], outs[0]["state_seqs"])
+
+
+def test_rollout_with_the_softbody_model_variant_vs_reference_golden(ag, dev):
+    """n_his = 5 / pstep = 4 / rel_input_dim 20 (config/dynamics/softbody.yaml) through the rollout driver: dynamics() takes
+    n_his from the task config (forward_dynamics.py:16).  Golden from the reference (rope task with n_his 5, the softbody
+    model); host-decoded and device-planned actions; teacher-forced edges at every forward."""
+    from helpers import load_golden, task_of, split_edges
+    g = load_golden("dyn_softbody_nhis5")
+    task = task_of(g)
+    assert task["n_his"] == 5 and int(g["pstep"]) == 4
+    mc, mat, ds = _cfg("softbody", 4)
+    ds = dict(ds, n_his=5)
+    m = ag.DynamicsPredictor(mc, mat, ds, dev)
+    m.load_state_dict({k[3:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith("w::")})
+    s0, a = torch.from_numpy(g["state0"]).to(dev), torch.from_numpy(g["action"]).to(dev)
+    out = ag.dynamics(s0, a, m, dev, _ppm(task, "softbody"))
+    assert torch.equal(out["action_seqs"].cpu(), torch.from_numpy(g["action_seqs"]))
+    assert np.abs(out["state_seqs"].cpu().numpy() - g["state_seqs"]).max() <= POS_TOL
+    tdev = dict(task, action_upper_lim=[0.0, 4.5, 3.14, 5.0])
+    dv = ag.dynamics(s0, a, m, dev, _ppm(tdev, "softbody"))
+    assert np.abs(dv["state_seqs"].cpu().numpy() - g["state_seqs"]).max() <= POS_TOL
+    sub = ag.dynamics(s0, a[1:2], m, dev, _ppm(task, "softbody"))["state_seqs"]
+    assert torch.equal(sub, out["state_seqs"][1:2])
+    N = g["state0"].shape[0] + 1
+    mask = torch.ones((3, N), dtype=torch.bool, device=dev)
+    tool = torch.zeros((3, N), dtype=torch.bool, device=dev)
+    tool[:, -1] = True
+    for i in range(int(g["n_steps"])):
+        el = ag.construct_edges_index(torch.from_numpy(g[f"step{i}::state_last"]).to(dev), task["adj_thresh"], mask, tool,
+                                      task["topk"], task["connect_tools_all"])
+        for (r, s), (wr, ws) in zip(_edges_to_lists(el), split_edges(g, f"step{i}::")):
+            assert np.array_equal(r, wr) and np.array_equal(s, ws), i
+    with pytest.raises(AssertionError, match="n_his"):
+        ag.dynamics(s0, a, m, dev, _ppm(dict(task, n_his=4), "softbody"))

@@ -36,7 +36,7 @@ def test_forward_per_particle_physics():
     assert np.abs(mot - g["pred_motion"]).max() < POS_TOL
 
 
-@pytest.mark.parametrize("name", ["dyn_rope", "dyn_granular", "dyn_cloth"])
+@pytest.mark.parametrize("name", ["dyn_rope", "dyn_granular", "dyn_cloth", "dyn_softbody_nhis5"])
 def test_dynamics_free_running(name):
     g = load_golden(name)
     W, task = O.weights_from_npz(g), task_of(g)
