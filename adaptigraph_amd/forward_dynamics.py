@@ -106,11 +106,8 @@ def _repeat_bound(task):
         return None
 
 
-def _run_device_actions(model, dev, task, ppm_optimizer, physics_param, action, state0, bound, sync, flags):
+def _run_device_actions(model, eng, dev, task, ppm_optimizer, physics_param, action, state0, bound, sync, flags):
     """ag_rollout_actions: decode + launch plan on the device (see module docstring)."""
-    if not isinstance(model, DynamicsPredictor):
-        raise TypeError("model must be an adaptigraph_amd.DynamicsPredictor")
-    eng = model.engine(dev)
     assert int(task["n_his"]) == model.n_his, "task_config['n_his'] (forward_dynamics.py:16) must be the model's n_his"
     B, H = action.shape[0], action.shape[1]
     N_o, M = state0.shape[0], ppm_optimizer.eef_num
@@ -151,13 +148,14 @@ def dynamics(state, action, model, device, ppm_optimizer, physics_param=None, _s
     dev = _require_gpu(device)
     B, H = action.shape[0], action.shape[1]
     if action.is_cuda and isinstance(model, DynamicsPredictor):
-        mode = model.engine(dev).get_option("device_decode")
+        eng = model.engine(dev)
+        mode = eng.get_option("device_decode")
         bound = _repeat_bound(task)
         if mode == 1 and bound is None:
             raise ValueError("option device_decode = 1 needs task_config['action_upper_lim'] (the bound of action_repeat)")
         if mode != 0 and bound is not None:
             state0 = state.detach().to(dev, torch.float32).contiguous()
-            out, decoded = _run_device_actions(model, dev, task, ppm_optimizer, physics_param, action, state0, bound,
+            out, decoded = _run_device_actions(model, eng, dev, task, ppm_optimizer, physics_param, action, state0, bound,
                                                _sync, _overflow_flag)
             return {"state_seqs": out, "action_seqs": decoded.to(action.device)}
     action_cpu = action.detach().to("cpu", torch.float32)

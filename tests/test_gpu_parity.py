@@ -330,7 +330,8 @@ def test_dynamics_repeat_zero_vs_reference_golden(ag, dev):
 
 def test_forward_softbody_variant_nhis5_vs_reference_golden(ag, dev):
     """config/dynamics/softbody.yaml: n_his = 5 (rel_input_dim 20), pstep = 4 - the eval-rollout path's model(**graph).
-    The rollout driver (planner path, n_his 4 in every task config) refuses such a model loudly."""
+    The bf16x3 arithmetic refuses such a model loudly; the rollout driver serves it since r03
+    (tests/test_gpu_more.py::test_rollout_with_the_softbody_model_variant_vs_reference_golden)."""
     g = load_golden("forward_softbody_nhis5")
     mc, mat, ds = _cfg("softbody", int(g["pstep"]))
     ds = dict(ds, n_his=5)
@@ -355,5 +356,7 @@ def test_forward_softbody_variant_nhis5_vs_reference_golden(ag, dev):
     task = dict(adj_thresh=0.4, topk=20, connect_tools_all=False, sim_real_ratio=10, push_length=0.2, gripper_enable=False,
                 max_n=1, max_nR=9000, n_his=5, eef_num=1, material="softbody", pusher_points=[[0, 0, 0.1]],
                 material_dims={"softbody": 1}, material_indices={"softbody": 0})
-    with pytest.raises(NotImplementedError, match="n_his"):
-        ag.dynamics(torch.zeros((10, 3), device=dev), torch.ones((1, 1, 4), device=dev), m, dev, _ppm(task, "softbody"))
+    cloud = torch.from_numpy(g["state"][0, -1, :40]).to(dev)
+    out = ag.dynamics(cloud, torch.tensor([[[float(cloud[:, 0].mean()), float(cloud[:, 2].mean()), 0.3, 2.5]]], device=dev), m,
+                      dev, _ppm(task, "softbody"))
+    assert out["state_seqs"].shape == (1, 1, 40, 3) and torch.isfinite(out["state_seqs"]).all()
