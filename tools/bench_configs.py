@@ -68,6 +68,7 @@ def homogeneous(mat, Bn, H, R, reps):
     rng = np.random.default_rng(0)
     cloud = cloud_of(mat, rng)
     task = task_of(mat, cloud.shape[0])
+    task["action_upper_lim"] = [0.0, 4.5, 3.14, float(R)]          # bounds the repeat: GPU-resident actions take ag_rollout_actions
     m, s0 = model_of(mat), torch.from_numpy(cloud).to(dev)
     a = torch.from_numpy(B.make_actions(Bn, H, R, cloud, rng)).to(dev)
     ppm = ppm_of(task, mat)

@@ -76,8 +76,15 @@ def loop_call(planner, s0, act_seq, n_chunk):
 
 
 def main():
-    n_sample, n_chunk, reps = 500, 40, 3
-    for mat in ("rope", "granular", "cloth"):
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--materials", default="rope,granular,cloth")
+    ap.add_argument("--modes", default="loop,chunked")
+    ap.add_argument("--sorts", default="1,0")
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    n_sample, n_chunk, reps = 500, 40, args.reps
+    for mat in args.materials.split(","):
         rng = np.random.default_rng(0)
         planner, m, s0, lo, hi, cloud, task = make_planner(mat, n_sample, rng)
         eng = m.engine(dev)
@@ -85,7 +92,9 @@ def main():
         act_seq = torch.rand((1, 4), device=dev) * (hi - lo) + lo
         for mode, fn in (("loop", lambda: loop_call(planner, s0, act_seq, n_chunk)),
                          ("chunked", lambda: planner.trajectory_optimization_chunked(s0, act_seq, n_chunk))):
-            for sort in (1, 0):
+            if mode not in args.modes.split(","):
+                continue
+            for sort in [int(x) for x in args.sorts.split(",")]:
                 with eng.options(repeat_sort=sort):
                     torch.manual_seed(1)
                     fn()
