@@ -98,7 +98,7 @@ def optimize_action_mppi(act_seqs, reward_seqs, reward_weight=100.0, action_lowe
 @torch.no_grad()
 def mpc_iteration(state_cur, act_seq, model_rollout_fn, evaluate_traj_fn, action_lower_lim, action_upper_lim, n_sample,
                   device, noise_level=1.0, reward_weight=500.0, push_length=0.10, iter_index=0, rollout_best=True,
-                  act_seqs=None, group=None, n_update_iter=1):
+                  act_seqs=None, group=None, n_update_iter=1, reuse_best_rollout=False):
     """Planner.trajectory_optimization_mppi (planner.py:234-277): per update iteration sample -> rollout -> evaluate ->
     MPPI update; the best candidate over all iterations is kept and (optionally) rolled out once more.  plan.py:199 runs
     it with n_update_iter = 1.
@@ -108,13 +108,15 @@ def mpc_iteration(state_cur, act_seq, model_rollout_fn, evaluate_traj_fn, action
     rank must call with the same generator state (or pass the same `act_seqs`, which then serves the first iteration).
     The whole candidate batch goes through one rollout call (the engine chunks on the device) and the cost maxima are
     taken over the whole batch; the reference's loop over n_sample / n_sample_chunk chunks with its chunk-local maxima
-    and merge_res (plan.py:241-247) is planner.Planner.trajectory_optimization_chunked."""
+    and merge_res (plan.py:241-247) is planner.Planner.trajectory_optimization_chunked.
+    reuse_best_rollout: take the best candidate's rollout out of the batch it was sampled in instead of rolling it out again
+    with a batch of one (exact on this engine - a candidate's rollout does not depend on its batch; single rank only)."""
     from .sharding import shard_bounds, all_gather_costs
     import torch.distributed as dist
     pg = None if group in (None, True) else group
     world = dist.get_world_size(pg) if group is not None else 1
     rank = dist.get_rank(pg) if group is not None else 0
-    best_act_seq = best_reward = reward_seqs = None
+    best_act_seq = best_reward = reward_seqs = best_rows = None
     nominal = act_seq
     for it in range(n_update_iter):
         if act_seqs is None or it > 0:
@@ -130,10 +132,14 @@ def mpc_iteration(state_cur, act_seq, model_rollout_fn, evaluate_traj_fn, action
         top = torch.argmax(reward_seqs)
         if best_reward is None or bool(reward_seqs[top] > best_reward):       # planner.py:254-260
             best_act_seq, best_reward = act_seqs[top], reward_seqs[top]
+            if reuse_best_rollout and world == 1:
+                n = act_seqs.shape[0]
+                best_rows = {k: (torch.index_select(v, 0, top.reshape(1)) if isinstance(v, torch.Tensor) and v.dim() > 0 and
+                                 v.shape[0] == n else v) for k, v in model_out.items()}
     out = {"act_seq": best_act_seq, "mppi_act_seq": nominal, "best_reward": best_reward, "reward_seqs": reward_seqs,
            "best_model_output": None, "best_eval_output": None}
     if rollout_best:                                                                   # planner.py:268-271
-        out["best_model_output"] = model_rollout_fn(state_cur, best_act_seq.unsqueeze(0))
+        out["best_model_output"] = best_rows if best_rows is not None else model_rollout_fn(state_cur, best_act_seq.unsqueeze(0))
         out["best_eval_output"] = evaluate_traj_fn(out["best_model_output"]["state_seqs"], best_act_seq.unsqueeze(0),
                                                    state_cur=state_cur)
     return out

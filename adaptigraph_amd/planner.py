@@ -107,6 +107,11 @@ class Planner(object):
         self.rollout_best = config.get("rollout_best", True)
         self.lr = config.get("lr", 1e-3)
         self.group = config.get("group", None)
+        # Optional, off by default (the reference's call pattern): the rollout of the best sampled sequence is taken from the
+        # batch it was sampled in instead of being computed again with a batch of one (planner.py:268-271).  Exact on this
+        # engine - a candidate's rollout does not depend on its batch, bit for bit - and NOT in general (a BLAS-backed
+        # rollout may round differently at another batch size), so it is the caller's statement about model_rollout_fn.
+        self.reuse_best_rollout = bool(config.get("reuse_best_rollout", False))
         self.chunk_id = 0
         self.total_chunks = 1
 
@@ -179,7 +184,7 @@ class Planner(object):
         """planner.py:234-277: n_update_iter rounds of sample -> rollout -> evaluate -> MPPI update; the best sampled
         sequence over all rounds is returned (not the MPPI mean) and, with rollout_best, rolled out once more."""
         model_outputs, eval_outputs = [], []
-        best_act_seq = best_reward = None
+        best_act_seq = best_reward = best_rows = None
         for i in range(self.n_update_iter):
             if self.verbose:
                 print(f"chunk: {self.chunk_id}/{self.total_chunks}, iter: {i}/{self.n_update_iter}")
@@ -194,13 +199,15 @@ class Planner(object):
             top = torch.argmax(reward_seqs)
             if i == 0 or reward_seqs[top] > best_reward:
                 best_act_seq, best_reward = act_seqs[top], reward_seqs[top]
+                if self.reuse_best_rollout:
+                    best_rows = self._pick(model_out, top, act_seqs.shape[0])
             if self.verbose:
                 model_outputs.append(model_out)
                 eval_outputs.append(eval_out)
         act_seq = best_act_seq
         best_model_out = best_eval_out = None
         if self.rollout_best:
-            best_model_out = self.model_rollout(state_cur, act_seq.unsqueeze(0))
+            best_model_out = best_rows if best_rows is not None else self.model_rollout(state_cur, act_seq.unsqueeze(0))
             best_eval_out = self.evaluate_traj(best_model_out["state_seqs"], act_seq.unsqueeze(0), state_cur=state_cur)
         return {"act_seq": act_seq,
                 "model_outputs": model_outputs if self.verbose else None,
@@ -228,6 +235,13 @@ class Planner(object):
         """rows [lo, hi) of every per-candidate tensor of a rollout / evaluation result"""
         return {k: (v[lo:hi] if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == total else v)
                 for k, v in out.items()}
+
+    @staticmethod
+    def _pick(out, index, total):
+        """row `index` (a 0-d index tensor: no host sync) of every per-candidate tensor of a rollout result, as a batch of one"""
+        idx = index.reshape(1)
+        return {k: (torch.index_select(v, 0, idx.to(v.device)) if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == total
+                    else v) for k, v in out.items()}
 
     @torch.no_grad()
     def trajectory_optimization_chunked(self, state_cur, act_seq, n_chunk):
@@ -265,6 +279,8 @@ class Planner(object):
             assert type(s) == torch.Tensor and s.shape == (S, H, A)
         c_lo, c_hi = shard_bounds(n_chunk, world, rank)
         winners = torch.zeros((c_hi - c_lo, H, A), dtype=samples[0].dtype, device=samples[0].device)
+        reuse = self.reuse_best_rollout and world == 1           # (sharded: the winners' rollouts live on other ranks)
+        picked = []
         if c_hi > c_lo:
             mine = torch.cat(samples[c_lo:c_hi], dim=0)
             model_out = self.model_rollout(state_cur, mine)
@@ -273,15 +289,18 @@ class Planner(object):
                 part = self._rows(model_out, j * S, (j + 1) * S, total)
                 reward_seqs = self._evaluate(part, samples[c_lo + j], state_cur)["reward_seqs"]
                 assert reward_seqs.shape == (S,)
-                winners[j] = samples[c_lo + j][torch.argmax(reward_seqs)]
+                top = torch.argmax(reward_seqs)
+                winners[j] = samples[c_lo + j][top]
+                if reuse:
+                    picked.append(self._pick(part, top, S))
         if world > 1:
             k = H * A
             bounds = [tuple(k * b for b in shard_bounds(n_chunk, world, r)) for r in range(world)]
             winners = all_gather_costs(winners.reshape(-1).contiguous(), n_chunk * k, pg, bounds=bounds).reshape(n_chunk, H, A)
-        best_out = self.model_rollout(state_cur, winners)
+        best_out = None if reuse else self.model_rollout(state_cur, winners)
         res_all = []
         for ci in range(n_chunk):
-            one = self._rows(best_out, ci, ci + 1, n_chunk)
+            one = picked[ci] if reuse else self._rows(best_out, ci, ci + 1, n_chunk)
             ev = self.evaluate_traj(one["state_seqs"], winners[ci:ci + 1], state_cur=state_cur)
             res_all.append({"act_seq": winners[ci], "model_outputs": None, "eval_outputs": None,
                             "best_model_output": one, "best_eval_output": ev})

@@ -920,6 +920,17 @@ def test_shipped_planner_configuration_chunked_equals_loop_at_size(ag, O, dev):
     assert torch.equal(fused["act_seq"], loop["act_seq"])
     assert torch.equal(fused["best_model_output"]["state_seqs"], loop["best_model_output"]["state_seqs"])
     assert torch.equal(fused["best_eval_output"]["reward_seqs"], loop["best_eval_output"]["reward_seqs"])
+    # the winners' rollouts sliced out of the big batch instead of rolled out again: the same bits (batch independence)
+    planner.reuse_best_rollout = True
+    torch.manual_seed(1)
+    sliced = planner.trajectory_optimization_chunked(s0, act_seq, 2)
+    torch.manual_seed(1)
+    sliced_loop = BP.loop_call(planner, s0, act_seq, 2)
+    planner.reuse_best_rollout = False
+    for r in (sliced, sliced_loop):
+        assert torch.equal(r["act_seq"], loop["act_seq"])
+        assert torch.equal(r["best_model_output"]["state_seqs"], loop["best_model_output"]["state_seqs"])
+        assert torch.equal(r["best_eval_output"]["reward_seqs"], loop["best_eval_output"]["reward_seqs"])
     # the 1000-candidate rollout ran exactly sum(action_repeat) candidate-forwards
     torch.manual_seed(1)
     a = torch.cat([planner.sample_action_sequences(act_seq, iter_index=0) for _ in range(2)])

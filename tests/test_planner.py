@@ -97,6 +97,33 @@ def test_chunk_loop_and_merge_match_reference_and_chunked_entry_equals_loop():
     assert torch.equal(a["act_seq"], b["act_seq"])
 
 
+def test_reuse_of_the_best_candidates_in_batch_rollout_is_exact_for_a_batch_independent_rollout():
+    """config['reuse_best_rollout'] (off by default): the best sequence's rollout is sliced out of its batch instead of being
+    rolled out again with a batch of one - same result dictionaries for a rollout that does not depend on the batch (the
+    closed-form stand-in here; the HIP engine on the GPU: tests/test_gpu_more.py), one rollout call less per chunk."""
+    g = load_golden("planner")
+    act0, state_cur = torch.from_numpy(g["act0"]), torch.from_numpy(g["state_cur"])
+    out = {}
+    for reuse in (False, True):
+        calls = []
+        pl = _planner(n_update_iter=2, reuse_best_rollout=reuse,
+                      model_rollout_fn=lambda s, a: (calls.append(a.shape[0]), toy_rollout(s, a))[1])
+        torch.manual_seed(35)
+        res = pl.trajectory_optimization(state_cur, act0.clone())
+        pl1 = _planner(n_update_iter=1, reuse_best_rollout=reuse,
+                       model_rollout_fn=lambda s, a: (calls.append(-a.shape[0]), toy_rollout(s, a))[1])
+        torch.manual_seed(36)
+        ch = pl1.trajectory_optimization_chunked(state_cur, act0.clone(), 3)
+        out[reuse] = (res, ch, list(calls))
+    (r0, c0, k0), (r1, c1, k1) = out[False], out[True]
+    assert k0 == [16, 16, 1, -48, -3] and k1 == [16, 16, -48]
+    for a, b in ((r0, r1), (c0, c1)):
+        assert torch.equal(a["act_seq"], b["act_seq"])
+        assert torch.equal(a["best_model_output"]["state_seqs"], b["best_model_output"]["state_seqs"])
+        assert a["best_model_output"]["state_seqs"].shape == b["best_model_output"]["state_seqs"].shape
+        assert torch.equal(a["best_eval_output"]["reward_seqs"], b["best_eval_output"]["reward_seqs"])
+
+
 def test_config_validation_and_gd():
     cfg = toy_planner_config(toy_rollout, toy_cost)
     bad = dict(cfg); bad.pop("n_sample")

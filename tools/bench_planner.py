@@ -79,7 +79,7 @@ def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--materials", default="rope,granular,cloth")
-    ap.add_argument("--modes", default="loop,chunked")
+    ap.add_argument("--modes", default="loop,chunked,loop_reuse,chunked_reuse")
     ap.add_argument("--sorts", default="1,0")
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
@@ -90,11 +90,24 @@ def main():
         eng = m.engine(dev)
         torch.manual_seed(0)
         act_seq = torch.rand((1, 4), device=dev) * (hi - lo) + lo
-        for mode, fn in (("loop", lambda: loop_call(planner, s0, act_seq, n_chunk)),
-                         ("chunked", lambda: planner.trajectory_optimization_chunked(s0, act_seq, n_chunk))):
+        def with_reuse(fn):
+            def run():
+                planner.reuse_best_rollout = True
+                try:
+                    return fn()
+                finally:
+                    planner.reuse_best_rollout = False
+            return run
+        loop_fn = lambda: loop_call(planner, s0, act_seq, n_chunk)
+        chunked_fn = lambda: planner.trajectory_optimization_chunked(s0, act_seq, n_chunk)
+        # *_reuse: config['reuse_best_rollout'] - the winners' rollouts are sliced out of their batches (exact on this engine)
+        for mode, fn in (("loop", loop_fn), ("chunked", chunked_fn), ("loop_reuse", with_reuse(loop_fn)),
+                         ("chunked_reuse", with_reuse(chunked_fn))):
             if mode not in args.modes.split(","):
                 continue
             for sort in [int(x) for x in args.sorts.split(",")]:
+                if mode.endswith("_reuse") and sort == 0:
+                    continue
                 with eng.options(repeat_sort=sort):
                     torch.manual_seed(1)
                     fn()
@@ -109,7 +122,7 @@ def main():
                     # candidate-forwards of the big rollout call(s): re-run one sampling + rollout of all candidates
                     torch.manual_seed(1)
                     a = torch.cat([planner.sample_action_sequences(act_seq, iter_index=0) for _ in range(n_chunk)])
-                    if mode == "loop":
+                    if mode.startswith("loop"):
                         for ci in range(n_chunk):
                             planner.model_rollout(s0, a[ci * n_sample:(ci + 1) * n_sample])
                             e, n = eng.rollout_counts()
