@@ -433,7 +433,7 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5", "--planner", "--fullsize", "--nhis5-rollout"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5", "--planner", "--fullsize", "--fullsize-more", "--nhis5-rollout"} & set(sys.argv)):
     main()
 
 # dynamics_masked for the other two materials: gripper offset + connect_tools_all (cloth) and the 5-point pusher
@@ -897,9 +897,11 @@ if __name__ == "__main__" and "--planner" in sys.argv:
 # whose GPU rollout left the oracle's after a near-tie in BENCH_r02).  The dense reference needs ~0.35 GB per cloth
 # candidate, so a handful of candidates is what it can do here.  Stored per forward: the edge list (int16 pairs + a
 # SHA-256 over the int32 lists), the prediction, the tool particles' positions; state_seqs.  Each file < 4 MB.
-def gen_fullsize(name, material, cloud, action, W, task_over, refs, cand_ids):
+def gen_fullsize(name, material, cloud, action, W, task_over, refs, cand_ids, masked=None):
+    """masked = (state_init (B,N_o,3), state_mask (B,N_o)): dynamics_masked instead of dynamics; `action` is then (B,1,4)
+    (stored in that shape, fed to the reference as (B,4)) and `cloud` only provides the particle count."""
     import hashlib
-    DynamicsPredictor, _, dynamics, _ = refs
+    DynamicsPredictor, _, dynamics, dynamics_masked = refs
     dyn, task = load_cfg(material)
     task = dict(task)
     task.update(task_over)
@@ -910,16 +912,25 @@ def gen_fullsize(name, material, cloud, action, W, task_over, refs, cand_ids):
     rec = Recorder(model)
     np.random.seed(0)
     t0 = time.time()
-    out = quiet(dynamics, torch.from_numpy(cloud), torch.from_numpy(action), model, torch.device("cpu"), ppm)
+    if masked is None:
+        out = quiet(dynamics, torch.from_numpy(cloud), torch.from_numpy(action), model, torch.device("cpu"), ppm)
+    else:
+        out = quiet(dynamics_masked, torch.from_numpy(masked[0]), torch.from_numpy(masked[1]), torch.from_numpy(action[:, 0]),
+                    model, torch.device("cpu"), ppm)
+        out = {k: v[:, None] for k, v in out.items()}           # (B,N,3) -> (B,1,N,3) like the unmasked layout
     dt = time.time() - t0
     B = action.shape[0]
     mask = torch.ones((B, N_o + M), dtype=torch.bool)
+    if masked is not None:
+        mask[:, :N_o] = torch.from_numpy(masked[1])
     tool = torch.zeros((B, N_o + M), dtype=torch.bool)
     tool[:, N_o:] = True
     for st in rec.steps:
         assert_no_topk_boundary_tie(torch.from_numpy(st["state_last"]), mask, tool, task["adj_thresh"], task["topk"])
     store = {"w::" + k: v for k, v in W.items()}
     store["state0"], store["action"] = cloud, action
+    if masked is not None:
+        store["state_init"], store["state_mask"] = masked
     store["cand_ids"] = np.asarray(cand_ids, np.int32)
     store["state_seqs"] = out["state_seqs"].numpy()
     store["action_seqs"] = out["action_seqs"].numpy()
@@ -971,8 +982,39 @@ def gen_fullsize_all():
     gen_fullsize("full_granular", "granular", gcloud, gact[[0]], W, {"max_nR": int(1.2 * 25 * 1029) + 64}, refs, [0])
 
 
+def gen_fullsize_more():
+    """rope 300+1 (BASELINE configs[1]: four candidates of tools/bench_configs.py's 64-candidate batch) and a masked cloth
+    case at size (configs[4] style: dynamics_masked, per-candidate particle counts 1400 and 2025 of 2025, 20 repeats)."""
+    refs = import_reference()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import bench as BN
+    W = BN.random_weights(0)
+    rng = np.random.default_rng(0)
+    t = np.linspace(0, 1, 300)
+    p = np.stack([-2 + 3 * t, 0 * t, 0.5 * np.sin(6 * t)], 1)
+    rcloud = (p + rng.normal(0, 0.01, p.shape)).astype(np.float32)
+    ract = BN.make_actions(64, 2, 10, rcloud, rng)
+    ids = [0, 21, 42, 63]
+    gen_fullsize("full_rope", "rope", rcloud, ract[ids], W, {"max_nR": int(1.2 * 11 * 301) + 64}, refs, ids)
+    rng = np.random.default_rng(1)
+    cloud = BN.cloth_cloud(45, rng)
+    N = cloud.shape[0]
+    counts = [1400, N]
+    state = np.zeros((2, N, 3), np.float32)
+    mask = np.zeros((2, N), bool)
+    for b, c in enumerate(counts):
+        keep = np.sort(rng.choice(N, c, replace=False))
+        state[b, :c] = cloud[keep]
+        mask[b, :c] = True
+    act = BN.make_actions(2, 1, 20, cloud, rng)
+    gen_fullsize("full_masked_cloth", "cloth", cloud, act, W, {"max_nR": int(1.2 * 6 * (N + 1)) + 64}, refs, [0, 1],
+                 masked=(state, mask))
+
+
 if __name__ == "__main__" and "--fullsize" in sys.argv:
     gen_fullsize_all()
+if __name__ == "__main__" and "--fullsize-more" in sys.argv:
+    gen_fullsize_more()
 
 
 

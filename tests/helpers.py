@@ -88,7 +88,8 @@ def fullsize_records(g, task):
             assert hashlib.sha256(r.tobytes() + s.tobytes()).digest() == sha[f, b].tobytes(), (f, b)
             li = int(np.searchsorted(starts, f, side="right") - 1)
             if f == starts[li]:
-                obj = g["state0"] if li == 0 else g["state_seqs"][b, li - 1]
+                start = g["state_init"][b] if "state_init" in g.files else g["state0"]      # masked variant: per-candidate clouds
+                obj = start if li == 0 else g["state_seqs"][b, li - 1]
             else:
                 obj = g["pred_pos"][f - 1, b]
             recs.append({"recv": r, "send": s, "pred_pos": g["pred_pos"][f, b],

@@ -21,8 +21,10 @@ POS_TOL_FWD = 5e-6     # one forward, identical inputs (BLAS summation order: to
 POS_TOL = 1e-5         # BASELINE north star, free-running
 
 
-def _masks(N_o, M):
+def _masks(N_o, M, obj_mask=None):
     mask = np.ones(N_o + M, bool)
+    if obj_mask is not None:
+        mask[:N_o] = obj_mask
     tool = np.zeros(N_o + M, bool)
     tool[N_o:] = True
     return mask, tool
@@ -32,16 +34,19 @@ def _masks(N_o, M):
     ("full_cloth_a", {0: "ok", 1023: "ok"}),
     ("full_cloth_flip", {49: "ok", 487: "ok"}),      # the reference does NOT flip where the GPU did: the oracle follows it
     ("full_granular", {0: "tie@18"}),                # the reference and the oracle part at a 1e-7 near-tie
+    ("full_rope", {0: "ok", 21: "ok", 42: "ok", 63: "ok"}),          # BASELINE configs[1] size: rope 300+1, top-k 10 binding
+    ("full_masked_cloth", {0: "ok", 1: "ok"}),       # dynamics_masked at size: 1400 and 2025 valid particles of 2025
 ])
 def test_oracle_vs_reference_at_full_size(name, expect):
     g = load_golden(name)
     W, task = O.weights_from_npz(g), task_of(g)
     N_o, M = g["state0"].shape[0], task["eef_num"]
-    mask, tool = _masks(N_o, M)
+    masked = "state_mask" in g.files
     per_cand = fullsize_records(g, task)
     # 1. teacher-forced edges at every forward, bit-exact; selection margin of the reference's own positions
     margins = []
     for b, (recs, _, _) in enumerate(per_cand):
+        mask, tool = _masks(N_o, M, g["state_mask"][b] if masked else None)
         mg = []
         for f, rec in enumerate(recs):
             r, s = O.construct_edges_single(rec["state_last"], task["adj_thresh"], mask, tool, task["topk"],
@@ -51,7 +56,11 @@ def test_oracle_vs_reference_at_full_size(name, expect):
         margins.append(mg)
     # 2. free-running oracle
     tr = []
-    out = O.dynamics(W, int(g["pstep"]), g["state0"], g["action"], task, trace=tr)
+    if masked:
+        out = O.dynamics_masked(W, int(g["pstep"]), g["state_init"], g["state_mask"], g["action"][:, 0], task, trace=tr)
+        out = {k: v[:, None] for k, v in out.items()}
+    else:
+        out = O.dynamics(W, int(g["pstep"]), g["state0"], g["action"], task, trace=tr)
     assert np.array_equal(out["action_seqs"], g["action_seqs"])
     tie_margin = 4.0 * task["adj_thresh"] * POS_TOL
     for b, (recs, capture, want) in enumerate(per_cand):

@@ -17,7 +17,7 @@ import torch
 
 from helpers import load_golden, task_of, fullsize_records
 from test_gpu_parity import _model, _ppm, POS_TOL
-from test_gpu_fullsize import _check_candidate, _per_step_unmasked
+from test_gpu_fullsize import _check_candidate, _per_step_unmasked, _per_step_masked
 
 pytestmark = pytest.mark.gpu
 
@@ -41,20 +41,30 @@ def O():
 
 
 @pytest.mark.parametrize("name,material,min_clean", [("full_cloth_a", "cloth", 1), ("full_cloth_flip", "cloth", 0),
-                                                     ("full_granular", "granular", 0)])
+                                                     ("full_granular", "granular", 0), ("full_rope", "rope", 2),
+                                                     ("full_masked_cloth", "cloth", 1)])
 def test_rollout_vs_reference_at_full_size(ag, O, dev, name, material, min_clean):
     g = load_golden(name)
     task = task_of(g)
     m = _model(ag, g, material, dev)
     ppm = _ppm(task, material)
     cloud, act = g["state0"], g["action"]
-    out = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(act).to(dev), m, dev, ppm)
+    masked = "state_mask" in g.files                                    # dynamics_masked: per-candidate clouds + masks
+    if masked:
+        st, mk = g["state_init"], g["state_mask"]
+        out = ag.dynamics_masked(torch.from_numpy(st).to(dev), torch.from_numpy(mk).to(dev), torch.from_numpy(act[:, 0]).to(dev),
+                                 m, dev, ppm)
+        out = {k: v[:, None] for k, v in out.items()}
+    else:
+        out = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(act).to(dev), m, dev, ppm)
     assert torch.equal(out["action_seqs"].cpu(), torch.from_numpy(g["action_seqs"]))
     seq = out["state_seqs"].cpu().numpy()
     verdicts = []
     for b, trace in enumerate(fullsize_records(g, task)):
-        v, err = _check_candidate(ag, O, dev, task, [x for x in seq[b]], trace,
-                                  lambda b=b: _per_step_unmasked(ag, m, dev, ppm, cloud, act[b]), cloud.shape[0],
+        steps_fn = (lambda b=b: _per_step_masked(ag, m, dev, ppm, st[b], mk[b], act[b, 0])) if masked else \
+                   (lambda b=b: _per_step_unmasked(ag, m, dev, ppm, cloud, act[b]))
+        v, err = _check_candidate(ag, O, dev, task, [x for x in seq[b]], trace, steps_fn, cloud.shape[0],
+                                  obj_mask=mk[b] if masked else None,
                                   label=f"{name} candidate {int(g['cand_ids'][b])}")
         verdicts.append((int(g["cand_ids"][b]), v, err))
     print(f"{name} vs the reference: " + ", ".join(f"cand {c}: {v} (err while within tolerance {e:.2e})" for c, v, e in verdicts))
