@@ -89,6 +89,21 @@ def test_two_rank_gloo_gather_matches_unsharded():
         assert sorted(res) == [(0, True), (1, True)]
 
 
+def test_four_rank_gloo_gather_matches_unsharded():
+    """world_size 4 (the 8-GPU node's collectives at half size): uneven shards 17/17/16/16, work-balanced ragged shards."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, 66, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(4)]
+
+
 # ------------------------------------------------------------------------------------------------- bench.py's step, 2 ranks
 def _mpc_step_worker(rank, world, port, B, q):
     """The function bench.py times (sharding.sharded_candidate_rewards) with the engine replaced by its CPU oracle:
