@@ -90,3 +90,18 @@ def test_host_shim_tool_layout_matches_oracle():
         oxz, odelta = O.tool_keypoints(odec, a[..., 2], task)
         assert np.array_equal(dec.numpy(), odec) and np.array_equal(rep.numpy(), orep)
         assert np.array_equal(xz.numpy(), oxz) and np.array_equal(delta.numpy(), odelta)
+
+
+def test_host_logic_of_the_action_path_choice():
+    """CPU-only host logic of dynamics(): the repeat bound comes from task_config['action_upper_lim'] (planning/*.yaml:28-29),
+    absent or malformed limits mean "decode on the host"."""
+    from adaptigraph_amd.forward_dynamics import _repeat_bound
+    assert _repeat_bound({"action_upper_lim": [0.0, 4.5, 3.14, 15]}) == 15
+    assert _repeat_bound({"action_upper_lim": [0.0, 4.5, 3.14, 10.9]}) == 10           # int(length) truncates (plan_utils.py:16)
+    assert _repeat_bound({}) is None and _repeat_bound({"action_upper_lim": None}) is None
+    assert _repeat_bound({"action_upper_lim": [1.0, 2.0]}) is None
+    from adaptigraph_amd import _lib
+    assert "device_decode" in _lib.OPTIONS and "repeat_sort" in _lib.OPTIONS
+    hdr = open(HEADER).read()
+    for name in _lib.OPTIONS:                                                          # every option is documented in the header
+        assert f'"{name}"' in hdr, name

@@ -69,6 +69,23 @@ def test_rollout_vs_reference_at_full_size(ag, O, dev, name, material, min_clean
         verdicts.append((int(g["cand_ids"][b]), v, err))
     print(f"{name} vs the reference: " + ", ".join(f"cand {c}: {v} (err while within tolerance {e:.2e})" for c, v, e in verdicts))
     assert sum(v == "ok" for _, v, _ in verdicts) >= min_clean, verdicts
+    if masked:
+        return
+    # the device-planned action path (ag_rollout_actions: decode, tool layout - 1-point / 5-point pusher, gripper - and launch
+    # plan on the GPU) against the same reference records: decoded actions to 1e-6, states by the same protocol
+    tdev = dict(task, action_upper_lim=[0.0, 4.5, 3.14, float(int(act[..., 3].max()))])
+    pdev = _ppm(tdev, material)
+    out_d = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(act).to(dev), m, dev, pdev)
+    assert float((out_d["action_seqs"].cpu() - torch.from_numpy(g["action_seqs"])).abs().max()) <= 1e-6
+    seq_d = out_d["state_seqs"].cpu().numpy()
+    vd = []
+    for b, trace in enumerate(fullsize_records(g, task)):
+        v, err = _check_candidate(ag, O, dev, tdev, [x for x in seq_d[b]], trace,
+                                  lambda b=b: _per_step_unmasked(ag, m, dev, pdev, cloud, act[b]), cloud.shape[0],
+                                  label=f"{name} candidate {int(g['cand_ids'][b])} (device-planned)")
+        vd.append((int(g["cand_ids"][b]), v, err))
+    print(f"{name} vs the reference, device-planned: " + ", ".join(f"cand {c}: {v} ({e:.2e})" for c, v, e in vd))
+    assert sum(v == "ok" for _, v, _ in vd) >= min_clean, vd
 
 
 @pytest.mark.parametrize("name,material", [("full_cloth_a", "cloth"), ("full_granular", "granular")])
