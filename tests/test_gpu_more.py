@@ -1046,3 +1046,34 @@ def test_rollout_with_the_softbody_model_variant_vs_reference_golden(ag, dev):
             assert np.array_equal(r, wr) and np.array_equal(s, ws), i
     with pytest.raises(AssertionError, match="n_his"):
         ag.dynamics(s0, a, m, dev, _ppm(dict(task, n_his=4), "softbody"))
+
+
+@pytest.mark.parametrize("material,cloud_fn", [("rope", lambda r: _rope(150, r)), ("cloth", lambda r: _grid(16, 0.3, 0.02, r))])
+def test_twenty_look_ahead_steps_of_one_repeat_vs_oracle(ag, O, dev, material, cloud_fn):
+    """SURVEY 8(d)'s secondary mapping of "horizon 20": n_look_forward = 20, length 1.5 (repeat 1) - the history is reset to the
+    captured state at every step (forward_dynamics.py:37-38) and every look-ahead step re-encodes the tool rows.  Host-decoded
+    and device-planned actions, against the oracle; a candidate whose repeat is 0 in the middle (zero slot, then a rollout
+    from the zero cloud) stays bit-equal between the two launch orders."""
+    rng = np.random.default_rng(107)
+    task = _task(material, max_nR=20000)
+    W, m = _model(ag, O, material, 107, dev)
+    cloud = cloud_fn(rng)
+    B, H = 6, 20
+    reps = np.ones((B, H), np.int64)
+    reps[2, 5:9] = 2                                                    # a few longer pushes in between
+    a_np = _actions(cloud, B, H, reps, rng, spread=0.5)
+    s0, a = torch.from_numpy(cloud).to(dev), torch.from_numpy(a_np).to(dev)
+    host = ag.dynamics(s0, a, m, dev, _ppm(task, material))
+    assert host["state_seqs"].shape == (B, H, cloud.shape[0], 3)
+    want = O.dynamics(W, 3, cloud, a_np, task)["state_seqs"]
+    err = np.abs(host["state_seqs"].cpu().numpy() - want).reshape(B, -1).max(1)
+    assert (err <= POS_TOL).sum() >= B - 1, err
+    tdev = dict(task, action_upper_lim=[0.0, 4.5, 3.14, 2.0])
+    devp = ag.dynamics(s0, a, m, dev, _ppm(tdev, material))
+    e2 = (devp["state_seqs"] - host["state_seqs"]).abs().reshape(B, -1).max(1).values
+    assert int((e2 <= POS_TOL).sum()) >= B - 1, e2
+    eng = m.engine(dev)
+    assert eng.rollout_counts() == (int(reps.sum()), int(reps.sum()))
+    with eng.options(repeat_sort=0):
+        unsorted = ag.dynamics(s0, a, m, dev, _ppm(tdev, material))
+    assert torch.equal(unsorted["state_seqs"], devp["state_seqs"])
