@@ -1052,8 +1052,7 @@ def test_rollout_with_the_softbody_model_variant_vs_reference_golden(ag, dev):
 def test_twenty_look_ahead_steps_of_one_repeat_vs_oracle(ag, O, dev, material, cloud_fn):
     """SURVEY 8(d)'s secondary mapping of "horizon 20": n_look_forward = 20, length 1.5 (repeat 1) - the history is reset to the
     captured state at every step (forward_dynamics.py:37-38) and every look-ahead step re-encodes the tool rows.  Host-decoded
-    and device-planned actions, against the oracle; a candidate whose repeat is 0 in the middle (zero slot, then a rollout
-    from the zero cloud) stays bit-equal between the two launch orders."""
+    and device-planned actions, against the oracle; the device plan's sorted and unsorted launch orders agree bit for bit."""
     rng = np.random.default_rng(107)
     task = _task(material, max_nR=20000)
     W, m = _model(ag, O, material, 107, dev)
