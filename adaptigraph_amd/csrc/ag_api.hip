@@ -93,7 +93,7 @@ const OptName kOptions[] = {
     {"repeat_sort", "AG_NO_REPEAT_SORT", &Options::repeat_sort, true},
     {"edge_wgs", "AG_EDGE_WGS", &Options::edge_wgs, false},       {"edge_block_min", "AG_EDGE_BLOCK_MIN", &Options::edge_block_min, false},
     {"enc_persist", "AG_ENC_PERSIST", &Options::enc_persist, false}, {"stagger_us", "AG_STAGGER_US", &Options::stagger_us, false},
-    {"device_decode", "AG_DEVICE_DECODE", &Options::device_decode, false},
+    {"device_decode", "AG_DEVICE_DECODE", &Options::device_decode, false}, {"zigzag", "AG_ZIGZAG", &Options::zigzag, false},
 };
 void options_from_env(Options& o) {
     for (const OptName& n : kOptions)
@@ -316,7 +316,7 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
         for (int k = 0; k < 2; ++k) w.g.UV[par][k] = s.take<float>(rows * NFP);
     w.g.C = s.take<float>(((size_t)Bc * c_cap + 256) * NFP);   // + room for the two self-loop constant rows
     w.g.B = Bc; w.g.N = N; w.g.n_inst = n_inst; w.g.edge_cap = edge_cap; w.g.c_cap = c_cap; w.g.n_p = N_o;
-    w.g.enc_persist = c->opt.enc_persist; w.g.stagger_us = c->opt.stagger_us; w.g.diag = c->diag;
+    w.g.enc_persist = c->opt.enc_persist; w.g.stagger_us = c->opt.stagger_us; w.g.zigzag = c->opt.zigzag; w.g.diag = c->diag;
     if (own_edges) {
         w.ell = s.take<int>(rows * (size_t)std::max(1, ell_stride));
         w.deg = s.take<int>(rows);

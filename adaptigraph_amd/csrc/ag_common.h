@@ -78,6 +78,10 @@ struct Options {
     int edge_block_min = -1;  // [AG_EDGE_BLOCK_MIN] rows per slice from which the 64-rows-per-wavefront schedule is used (-1: built-in)
     int enc_persist = 0;      // [AG_ENC_PERSIST]    persistent workgroups of k_edge_enc (0 = one per tile)
     int stagger_us = 0;       // [AG_STAGGER_US]     offset between the two workgroups of a CU in the propagate chains
+    int zigzag = 1;           // [AG_ZIGZAG]         odd message-passing rounds walk the row tiles backwards: what the previous round
+                              //                     read last from HBM is read first, while it is still in the 256-MB Infinity Cache
+                              //                     (one stream: k_node_prop 170.5 -> 168.3, final round 83.4 -> 81.4 ms per rollout;
+                              //                     four streams: 477.3 -> 475.8 ms - the other chunks' traffic evicts most of it)
     int device_decode = -1;   // [AG_DEVICE_DECODE]  consumed by the Python shim: dynamics() hands GPU-resident actions to
                               //                     ag_rollout_actions (-1: when the task config bounds the repeat, 0 never, 1 always)
 };
@@ -170,7 +174,7 @@ struct GraphBufs {
     // edges) appended to the list; k_roll_update applies it to the masked-out rows of every real candidate.
     const int* rowlist; const int* n_rows; // (B*N + N_o,), (1,) device; null = all rows
     int n_his;                             // 4 (0 = 4), or 5 on the forward path (feature rows then have pitch F15_PITCH)
-    int enc_persist, stagger_us;           // Options of the owning context
+    int enc_persist, stagger_us, zigzag;   // Options of the owning context
     void* diag;                            // diagnostic build (-DAG_DIAG, ag_diag.hip) only: the context's probe state, else null
 };
 constexpr int B3_PHASE_BYTES = 2 * 5 * 3 * 64 * 16;   // 30,720

@@ -280,6 +280,7 @@ struct GDev {
     // first round of a rollout step, else what the previous round's chain wrote) - never the buffers this launch writes
     const float* Uin; const float* Vin; const int* deg; int ell_stride; int dedupe; unsigned self_row; const int* n_guard;
     int stagger_ticks; unsigned first_wave;   // see stagger_second_workgroup
+    int reverse;                              // k_node_prop: walk the row tiles from the last to the first (Options::zigzag)
     unsigned n_tiles;                         // k_edge_enc: > 0 = persistent workgroups (AG_ENC_PERSIST) over this many tiles
     // ragged batches (masked rollouts): the propagate chains walk a compact list of the rows that exist - valid object
     // particles and tools, plus one phantom candidate that stands for every masked-out particle (GraphBufs) - instead of
@@ -658,8 +659,9 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* stg = lds + 2 * BUF_FLOATS + wave * STG_FLOATS;
     const long nrows = g.n_rows ? (long)*g.n_rows : (long)g.B * g.N;     // work-list slots (== dense rows without a list)
-    if ((long)blockIdx.x * WG_ROWS >= nrows) return;                      // whole workgroup past the end of a ragged batch
-    const long slot = (long)blockIdx.x * WG_ROWS + wave * 32 + (lane & 31);
+    const unsigned bid = g.reverse ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    if ((long)bid * WG_ROWS >= nrows) return;                             // whole workgroup past the end of a ragged batch
+    const long slot = (long)bid * WG_ROWS + wave * 32 + (lane & 31);
     const bool valid = slot < nrows;
     const long rowc = dense_row(g, slot, nrows);
     const long row = rowc;
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     Act x, y;
     // The residual terms seed the accumulator: y = P + eff, then y += Wb*agg.  All three row loads are issued here,
     // together, instead of two of them stalling the chain after the Wb layer.
-    gather_agg(g, stg, (long)blockIdx.x * WG_ROWS + wave * 32, nrows, x, lane);
+    gather_agg(g, stg, (long)bid * WG_ROWS + wave * 32, nrows, x, lane);
     __builtin_amdgcn_sched_barrier(0);                       // nothing of what follows is worth a register during the gather
 #ifdef AG_DIAG
     if (g.dbg && tid == 0) g.dbg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1069,7 +1071,7 @@ static GDev to_dev(const float* w, const GraphBufs& g) {
     // Options::stagger_us: offset between the two workgroups of a CU in the fused propagate chains.  Off by default: it removes
     // the "both computing / both gathering" states (probe: 8 % -> 0 % of CU time) but the kernel time moves by <= 1 %
     // either way (two streams: 169 vs 171 ms per rollout with 30 us; four streams: 484.9 vs 482.9 ms per rollout without)
-    d.stagger_ticks = g.stagger_us * 100; d.first_wave = 512;
+    d.stagger_ticks = g.stagger_us * 100; d.first_wave = 512; d.reverse = 0;
 #ifdef AG_DIAG
     d.dbg = nullptr;
 #endif
@@ -1122,6 +1124,7 @@ static void set_round(GDev& d, const GraphBufs& g, int round) {
     d.Uin = cls ? g.c_U : g.UV[(round - 1) & 1][0];         // round 0 without a class table: k_node_enc wrote parity 1
     d.Vin = cls ? g.c_V : g.UV[(round - 1) & 1][1];
     d.U = g.UV[round & 1][0]; d.V = g.UV[round & 1][1];
+    d.reverse = g.zigzag ? (round & 1) : 0;
 }
 hipError_t launch_node_prop(const float* w, const GraphBufs& g, int round, hipStream_t st) {
     GDev d = to_dev(w, g);

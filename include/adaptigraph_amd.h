@@ -117,6 +117,8 @@ int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
  *   "edge_block_min" [AG_EDGE_BLOCK_MIN]  rows per slice from which the 64-rows-per-wavefront schedule is used (-1 = built-in 256)
  *   "enc_persist"    [AG_ENC_PERSIST]     persistent workgroups of k_edge_enc (default 0 = one workgroup per tile)
  *   "stagger_us"     [AG_STAGGER_US]      start offset between the two workgroups of a CU in the propagate chains (default 0)
+ *   "zigzag"         [AG_ZIGZAG]          odd message-passing rounds walk the row tiles backwards (default 1; Infinity-Cache reuse of
+ *                                         the C rows the previous round read last)
  *   "device_decode"  [AG_DEVICE_DECODE]   consumed by the Python shim: dynamics() with GPU-resident actions goes through
  *                                         ag_rollout_actions: -1 when task_config bounds the repeat (default), 0 never, 1 always
  * Unknown names return AG_ERR_INVALID. */
