@@ -105,3 +105,18 @@ def test_host_logic_of_the_action_path_choice():
     hdr = open(HEADER).read()
     for name in _lib.OPTIONS:                                                          # every option is documented in the header
         assert f'"{name}"' in hdr, name
+
+
+def test_header_is_plain_c99_and_the_c_client_compiles_against_it(tmp_path):
+    """The boundary is C, not C++: the header passes gcc -std=c99 -pedantic -Werror, and the plain-C client of it
+    (tools/abi_client/abi_client.c, run on the GPU by tests/test_gpu_abi_client.py) compiles against it."""
+    tu = tmp_path / "t.c"
+    tu.write_text('#include "adaptigraph_amd.h"\nint main(void) { return (int)(ag_abi_version() != AG_ABI_VERSION); }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", str(tu)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    if os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I",
+                            os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", "-fsyntax-only",
+                            os.path.join(ROOT, "tools", "abi_client", "abi_client.c")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
