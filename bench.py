@@ -248,8 +248,26 @@ def main():
     picks = sorted({int(round(i * (hi - lo - 1) / max(1, n_pick - 1))) for i in range(n_pick)})
     timed_seqs = last["seq"][picks].cpu().numpy() if picks else None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    multi = None
     if world > 1:
+        # diagnostics for a multi-GPU run (not part of `value`): every rank's own wall time of the timed region, and the
+        # latency of the step's exchange alone (MAX all-reduce of two scalars + all-gather of the B/N rewards)
+        per_rank = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per_rank, tmax.clone())
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        probe = torch.zeros(hi - lo, device=dev)
+        two = torch.zeros(2, device=dev)
+        from adaptigraph_amd.sharding import all_gather_costs as _agc
+        for _ in range(3):
+            dist.all_reduce(two, op=dist.ReduceOp.MAX); _agc(probe, B)
+        sync_all()
+        tc = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(two, op=dist.ReduceOp.MAX); _agc(probe, B)
+        sync_all()
+        multi = {"per_rank_ms_per_step": [float(t.item()) / args.steps * 1e3 for t in per_rank],
+                 "exchange_us_per_step": (time.perf_counter() - tc) / 20 * 1e6,
+                 "backend": dist.get_backend(), "candidates_per_rank": [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]}
     dt = float(tmax.item())
     # ---- roofline pass: the same rollout once more with HIP events around every launch of the profiled kernels, on
     # the stream they are launched on.  Profiling pins the engine to ONE stream: with two chunks sharing the GPU an
@@ -397,6 +415,8 @@ def main():
             # bit for bit (tests/test_gpu_two_ranks.py compares the 2-rank line with the 1-rank line)
             "reward_sha256": __import__("hashlib").sha256(costs.detach().cpu().numpy().tobytes()).hexdigest(),
         }
+        if multi is not None:
+            line["multi_gpu"] = multi
         # whole-rollout arithmetic rate: FLOPs the kernels execute per rollout step and candidate
         # (encoded edges x 140,100 + particles x (2 x 135,000 + 135,900) + 8 N^2 for the graph), and the reference
         # formulation's F_ref = N*361,800 + N_o*90,900 + E*500,100 + 8 N^2 over the same time ("effective")

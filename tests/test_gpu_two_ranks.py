@@ -46,3 +46,5 @@ def test_two_ranks_on_one_gpu_equal_one_rank_bitwise():
     assert l2["config"]["candidates"] == 64 and "sharded over 2 GPU(s)" in l2["config"]["parallelism"]
     assert l1["reward_sha256"] == l2["reward_sha256"], (l1["reward_sha256"], l2["reward_sha256"])
     assert l2["value"] > 0 and l2["scaling"] == "strong"
+    mg = l2["multi_gpu"]                                                 # per-rank times and the exchange's latency, for a real SCALE run
+    assert mg["candidates_per_rank"] == [32, 32] and len(mg["per_rank_ms_per_step"]) == 2 and mg["exchange_us_per_step"] > 0
