@@ -222,7 +222,9 @@ int ag_rollout_async(ag_ctx* ctx, void* stream, const ag_rollout_params* p, cons
  *   d_flags         (>= 2 int32, device, caller-zeroed): [0] max edge count seen if it exceeded max_nR (as ag_rollout_async),
  *                   [1] largest action_repeat seen if it exceeded max_repeat (the results of such a candidate are invalid)
  * cos / sin are the device's: decoded values agree with a host decode to an ulp or two (a CUDA-resident reference would
- * use device transcendental functions too); everything downstream is the same arithmetic as ag_rollout. y_mode must be 0. */
+ * use device transcendental functions too); everything downstream is the same arithmetic as ag_rollout. y_mode must be 0
+ * (the masked variant takes host-decoded actions), M <= 8, 0 <= max_repeat <= 1024 (AG_ERR_INVALID / AG_ERR_UNSUPPORTED
+ * otherwise). */
 int ag_rollout_actions(ag_ctx* ctx, void* stream, const ag_rollout_params* p, const float* d_state0, const float* d_action,
                        float push_length, const float* h_tool_offsets, int32_t max_repeat, const float* d_phys_vec,
                        float* d_state_seqs, float* d_action_seqs, int32_t* d_flags);
