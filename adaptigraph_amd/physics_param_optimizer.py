@@ -13,31 +13,30 @@ from .forward_dynamics import dynamics_masked
 from .losses import mean_chamfer
 
 
+def _pad_clouds(clouds, rows, device):
+    """list of (n_i, 3) arrays -> ((len, rows, 3) float32, (len, rows) bool) on `device`: cloud i in the first n_i rows"""
+    pad = np.zeros((len(clouds), rows, 3), np.float32)
+    valid = np.zeros((len(clouds), rows), bool)
+    for i, cloud in enumerate(clouds):
+        pad[i, :len(cloud)] = cloud
+        valid[i, :len(cloud)] = True
+    return torch.from_numpy(pad).to(device), torch.from_numpy(valid).to(device)
+
+
 def dynamics_error(physics_param, ppm_optimizer, state_init_list, state_real_list, actions):
-    len_act = len(actions)
-    physics_param = copy.deepcopy(physics_param)
+    """physics_param: a list / array of values for the single material (what gp_minimize / cma hand over, :183-186) or a
+    {material: tensor} dict; state_*_list: per past interaction the observed cloud before / after the push; actions: the pushes.
+    -> mean over the interactions of the masked chamfer distance between the predicted and the observed cloud (:219-226)."""
     device = ppm_optimizer.device
-    if isinstance(physics_param, (list, np.ndarray)):                                  # :183-186
-        assert len(list(ppm_optimizer.material_dims.keys())) == 1, "only support single material now"
-        material_name = list(ppm_optimizer.material_dims.keys())[0]
-        physics_param = {material_name: torch.tensor(physics_param, dtype=torch.float32)}
-    max_nobj = ppm_optimizer.task_config["max_nobj"]
-    init_mask = np.zeros((len_act, max_nobj), bool)
-    final_mask = np.zeros((len_act, max_nobj), bool)
-    init_pad = np.zeros((len_act, max_nobj, 3), np.float32)
-    final_pad = np.zeros((len_act, max_nobj, 3), np.float32)
-    for i in range(len_act):                                                           # :196-208
-        ni, nf = state_init_list[i].shape[0], state_real_list[i].shape[0]
-        init_mask[i, :ni] = True
-        final_mask[i, :nf] = True
-        init_pad[i, :ni] = state_init_list[i]
-        final_pad[i, :nf] = state_real_list[i]
-    state_init_all = torch.from_numpy(init_pad).to(device)
-    state_init_mask = torch.from_numpy(init_mask).to(device)
-    state_final_all = torch.from_numpy(final_pad).to(device)
-    state_final_mask = torch.from_numpy(final_mask).to(device)
-    acts = torch.from_numpy(np.stack(actions, axis=0).astype(np.float32)).to(device)
-    out = dynamics_masked(state_init_all, state_init_mask, acts, ppm_optimizer.model, device, ppm_optimizer,
-                          physics_param=physics_param)                                 # :219-220
-    error = mean_chamfer(out["state_seqs"].detach(), state_final_all, state_init_mask, state_final_mask)   # :223
-    return error.mean()
+    if isinstance(physics_param, (list, np.ndarray)):
+        names = list(ppm_optimizer.material_dims.keys())
+        assert len(names) == 1, "only support single material now"
+        physics_param = {names[0]: torch.tensor(np.asarray(physics_param), dtype=torch.float32)}
+    else:
+        physics_param = copy.deepcopy(physics_param)
+    rows = ppm_optimizer.task_config["max_nobj"]
+    before, before_valid = _pad_clouds(state_init_list[:len(actions)], rows, device)
+    after, after_valid = _pad_clouds(state_real_list[:len(actions)], rows, device)
+    pushes = torch.from_numpy(np.stack(actions, axis=0).astype(np.float32)).to(device)
+    rolled = dynamics_masked(before, before_valid, pushes, ppm_optimizer.model, device, ppm_optimizer, physics_param=physics_param)
+    return mean_chamfer(rolled["state_seqs"].detach(), after, before_valid, after_valid).mean()
