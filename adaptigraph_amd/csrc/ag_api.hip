@@ -297,7 +297,7 @@ size_t work_bytes(int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices
     size_t bytes = 16 * 256;
     bytes += rows * (NODE_IN + F15_PITCH + (own_group ? n_inst : 0)) * 4 + 6 * rows * NFP * 4 + ((size_t)Bc * c_cap + 256) * NFP * 4;
     if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 3) * 4 + 3 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
-    if (roll) bytes += rows * 4 + 1024 + (size_t)Bc * N_HIS_MAX * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
+    if (roll) bytes += rows * 4 + 1024 + (size_t)Bc * 4 + (size_t)Bc * N_HIS_MAX * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
                        (size_t)cls_rows(N_o, N - N_o, Bc) * (NODE_IN + 4 * NFP) * 4;
     return bytes + 64 * 256;
 }
@@ -332,7 +332,7 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
     }
     if (roll) {
         w.rowlist = s.take<int>(rows);
-        w.n_rows = s.take<int>(64);
+        w.n_rows = s.take<int>((size_t)Bc + 64);            // ragged batches: row count per number of live slots (k_build_rowlist)
         w.r.hist = s.take<float>((size_t)Bc * N_HIS_MAX * N * 3);   // (Bc, n_his, N, 3) with the model's n_his (4 or 5)
         w.r.pred = s.take<float>((size_t)Bc * N_o * 3);
         w.r.motion = s.take<float>((size_t)Bc * N_o * 3);
@@ -833,8 +833,9 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     // launched over that prefix only.  Executed candidate-forwards = sum of action_repeat, exactly.  A slot's candidate
     // may change between look-ahead steps: the state carried from one to the next lives in d_state_seqs, which k_roll_init
     // reads by candidate id.  Candidates are independent, so every candidate's result is bit-identical to the unsorted
-    // order's.  Ragged batches keep their slot order (their row list is built once per call).
-    const bool sort_on = c->opt.repeat_sort && !ragged;
+    // order's.  Ragged batches (one look-ahead step) build their row list in the sorted slot order, with the row count of
+    // every live prefix tabulated beside it.
+    const bool sort_on = c->opt.repeat_sort != 0;
     const int n_chunks_all = (p->B + Bc - 1) / Bc;
     int* h_cand = nullptr;
     // device plan: pointers into c->d_plan
@@ -939,7 +940,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             HIPCHK(c, hipMemcpyAsync(w.g.C + (size_t)g.self_row * NFP, c->d_cself, 2 * NFP * 4, hipMemcpyDeviceToDevice, cs));
         }
         RollArgs ra{};
-        ra.B = nb; ra.N_o = p->N_o; ra.M = p->M; ra.H = p->H; ra.y_mode = p->y_mode; ra.b0 = b0;
+        ra.B = nb; ra.B_slots = nb; ra.N_o = p->N_o; ra.M = p->M; ra.H = p->H; ra.y_mode = p->y_mode; ra.b0 = b0;
         ra.grip = p->gripper_offset; ra.grip_on = p->gripper_enable; ra.phys = p->physics_param; ra.phys_vec = d_phys_vec;
         ra.state0 = d_state0; ra.state0_batched = p->y_mode == 1; ra.obj_mask = d_obj_mask;
         ra.eef_xz = d_eef_xz; ra.eef_delta = d_eef_delta; ra.repeat = dev_plan ? pl_repeat : c->d_repeat; ra.state_seqs = d_state_seqs;
@@ -956,10 +957,11 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             g.deg = w.deg; g.ell_stride = k + p->M;
         }
         w.r.ragged = ragged ? 1 : 0; w.r.clamp = c->dims.motion_clamp;
-        if (ragged) {   // the mask does not change during a rollout: one work list per chunk and call
-            HIPCHK(c, launch_build_rowlist(d_obj_mask, b0, nb, p->N_o, p->M, w.rowlist, w.n_rows, w.r.mask, w.deg, cs));
+        if (ragged) {   // the mask does not change during a rollout: one work list per chunk and call, in slot order (H = 1)
+            const int* d_cand0 = sort_on ? c->d_repeat + nrep + b0 : nullptr;
+            HIPCHK(c, launch_build_rowlist(d_obj_mask, d_cand0, b0, nb, p->N_o, p->M, w.rowlist, w.n_rows, w.r.mask, w.deg, cs));
             HIPCHK(c, hipMemsetAsync(w.row_ptr + (size_t)nb * (N + 1), 0, (size_t)(N + 1) * 4, cs));   // CSR path: no edges
-            g.rowlist = w.rowlist; g.n_rows = w.n_rows;
+            g.rowlist = w.rowlist; g.n_rows = w.n_rows + nb;
         }
         for (int li = 0; li < p->H; ++li) {
             const int* seg = dev_plan ? nullptr : h_cand + (size_t)li * p->B + b0;   // slot -> candidate of this chunk and look-ahead step
@@ -985,6 +987,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
                 } else {
                     if (sort_on) while (n_live > 0 && h_repeat[(size_t)seg[n_live - 1] * p->H + li] < ai) --n_live;   // descending order: a prefix
                     c->fwd_executed += n_live;
+                    if (ragged) g.n_rows = w.n_rows + n_live;   // rows of the live slots (+ the phantom candidate's)
                 }
                 ea.B = n_live; g.B = n_live; ra.B = n_live;
                 HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));

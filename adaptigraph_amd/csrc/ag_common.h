@@ -172,7 +172,7 @@ struct GraphBufs {
     // on the candidate, so what the reference computes for it (model.py:338: pos + clamp(motion), a constant motion per
     // particle index) is computed ONCE, on the rows of a phantom candidate B (all particles masked out, no tools, no
     // edges) appended to the list; k_roll_update applies it to the masked-out rows of every real candidate.
-    const int* rowlist; const int* n_rows; // (B*N + N_o,), (1,) device; null = all rows
+    const int* rowlist; const int* n_rows; // (B*N + N_o,), device int; null = all rows
     int n_his;                             // 4 (0 = 4), or 5 on the forward path (feature rows then have pitch F15_PITCH)
     int enc_persist, stagger_us, zigzag;   // Options of the owning context
     void* diag;                            // diagnostic build (-DAG_DIAG, ag_diag.hip) only: the context's probe state, else null
@@ -204,7 +204,8 @@ struct RollBufs {
     uint8_t* tool;      // (B,N)
 };
 struct RollArgs {
-    int B, N_o, M, H, li, ai, y_mode, b0;  // b0 = first candidate of this chunk in the full batch
+    int B, N_o, M, H, li, ai, y_mode, b0;  // B = slots this launch covers; b0 = first candidate of this chunk in the full batch
+    int B_slots;                           // slots of the chunk (the phantom candidate of a ragged batch sits behind them)
     float grip; int grip_on; float phys;
     int write_obj_cls;                        // roll_init also writes the object rows of the class table
     const float* phys_vec;                    // null or (N_o,) per-particle physics parameter
@@ -250,9 +251,10 @@ struct RollPlan {
 };
 hipError_t launch_roll_plan(const RollPlan& p, hipStream_t st);
 
-// work list of a ragged batch (see GraphBufs::rowlist): valid rows of candidates [0,B) + phantom rows if any particle is
-// masked out; also clears the phantom candidate's mask and degree rows
-hipError_t launch_build_rowlist(const uint8_t* obj_mask, int b0, int B, int N_o, int M, int* rowlist, int* n_rows,
+// work list of a ragged batch (see GraphBufs::rowlist): phantom rows (if any particle is masked out), then the valid rows of
+// slots [0,B) in slot order; tab (B+1 ints): entries when only the first n slots are live; cand: slot -> candidate or null;
+// also clears the phantom candidate's mask and degree rows
+hipError_t launch_build_rowlist(const uint8_t* obj_mask, const int* cand, int b0, int B, int N_o, int M, int* rowlist, int* tab,
                                 uint8_t* mask, int* deg, hipStream_t st);
 hipError_t launch_roll_init(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);
 hipError_t launch_roll_update(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);

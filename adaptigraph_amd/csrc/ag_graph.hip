@@ -251,25 +251,40 @@ __global__ __launch_bounds__(RT) void k_roll_update(RollDev d) {
     }
 }
 
-// Work list of a ragged batch (GraphBufs::rowlist).  One workgroup; rows in ascending dense order: for every candidate its
-// valid object particles, then its tools; then - only if some particle of the chunk is masked out - the N_o object rows of
-// the phantom candidate B.  Also clears what the chains read of the phantom candidate (validity mask, in-degrees).
-__global__ __launch_bounds__(RT) void k_build_rowlist(const uint8_t* __restrict__ obj_mask, int b0, int B, int N_o, int M,
-                                                       int* __restrict__ rowlist, int* __restrict__ n_rows,
+// Work list of a ragged batch (GraphBufs::rowlist).  One workgroup.  Layout: first - only if some particle of the chunk is
+// masked out - the N_o object rows of the phantom candidate (slot B), then for every slot s = 0..B-1 (in slot order, i.e. the
+// repeat-sorted launch order) its valid object particles and its tools.  tab[n] = number of entries when only the first n slots
+// are live (phantom rows included), n = 0..B: the launches of a step take their row count from tab + n_live.  `cand`: slot ->
+// candidate of the full batch (null: b0 + slot).  Also clears what the chains read of the phantom candidate (validity mask,
+// in-degrees).
+__global__ __launch_bounds__(RT) void k_build_rowlist(const uint8_t* __restrict__ obj_mask, const int* __restrict__ cand, int b0,
+                                                       int B, int N_o, int M, int* __restrict__ rowlist, int* __restrict__ tab,
                                                        uint8_t* __restrict__ mask, int* __restrict__ deg) {
     __shared__ int scan[RT];
     __shared__ int base;
+    __shared__ int any_invalid;
     const int tid = threadIdx.x, N = N_o + M;
-    if (tid == 0) base = 0;
+    if (tid == 0) { base = 0; any_invalid = 0; }
     for (int i = tid; i < N; i += RT) { mask[(long)B * N + i] = 0; if (deg) deg[(long)B * N + i] = 0; }
     __syncthreads();
     const long total = (long)B * N;
+    int bad = 0;
+    for (long r = tid; r < total; r += RT) {
+        const int b = (int)(r / N), i = (int)(r - (long)b * N);
+        if (i < N_o && !obj_mask[(long)(cand ? cand[b] : b0 + b) * N_o + i]) bad = 1;
+    }
+    if (bad) any_invalid = 1;                                // (benign race: every writer stores 1)
+    __syncthreads();
+    const int n_ph = any_invalid ? N_o : 0;
+    for (int i = tid; i < n_ph; i += RT) rowlist[i] = (int)(total + i);
+    if (tid == 0) { base = n_ph; tab[0] = n_ph; }
+    __syncthreads();
     for (long r0 = 0; r0 < total; r0 += RT) {
         const long r = r0 + tid;
         int v = 0;
         if (r < total) {
             const int b = (int)(r / N), i = (int)(r - (long)b * N);
-            v = (i >= N_o || obj_mask[(long)(b0 + b) * N_o + i]) ? 1 : 0;
+            v = (i >= N_o || obj_mask[(long)(cand ? cand[b] : b0 + b) * N_o + i]) ? 1 : 0;
         }
         scan[tid] = v;
         __syncthreads();
@@ -281,18 +296,16 @@ __global__ __launch_bounds__(RT) void k_build_rowlist(const uint8_t* __restrict_
             __syncthreads();
         }
         if (v) rowlist[base + scan[tid] - 1] = (int)r;
+        // the last row of a slot closes that slot's prefix
+        if (r < total && (r + 1) % N == 0) tab[(r + 1) / N] = base + scan[tid];
         __syncthreads();
         if (tid == RT - 1) base += scan[RT - 1];
         __syncthreads();
     }
-    const int n_valid = base;
-    const bool any_invalid = n_valid < total;
-    if (any_invalid) for (int i = tid; i < N_o; i += RT) rowlist[n_valid + i] = (int)(total + i);
-    if (tid == 0) n_rows[0] = n_valid + (any_invalid ? N_o : 0);
 }
-hipError_t launch_build_rowlist(const uint8_t* obj_mask, int b0, int B, int N_o, int M, int* rowlist, int* n_rows,
+hipError_t launch_build_rowlist(const uint8_t* obj_mask, const int* cand, int b0, int B, int N_o, int M, int* rowlist, int* tab,
                                 uint8_t* mask, int* deg, hipStream_t st) {
-    hipLaunchKernelGGL(k_build_rowlist, dim3(1), dim3(RT), 0, st, obj_mask, b0, B, N_o, M, rowlist, n_rows, mask, deg);
+    hipLaunchKernelGGL(k_build_rowlist, dim3(1), dim3(RT), 0, st, obj_mask, cand, b0, B, N_o, M, rowlist, tab, mask, deg);
     return hipGetLastError();
 }
 
@@ -389,7 +402,7 @@ hipError_t launch_roll_plan(const RollPlan& p, hipStream_t st) {
 static RollDev to_dev(const RollArgs& a, const RollBufs& r, const GraphBufs& g) {
     RollDev d;
     d.a = a; d.hist = r.hist; d.pred = r.pred; d.mask = r.mask; d.tool = r.tool;
-    d.motion_inv = r.ragged ? r.motion + (long)a.B * a.N_o * 3 : nullptr; d.clamp = r.clamp;
+    d.motion_inv = r.ragged ? r.motion + (long)a.B_slots * a.N_o * 3 : nullptr; d.clamp = r.clamp;   // the phantom slot's rows
     d.node_in = g.node_in; d.feat12 = g.feat12; d.group = g.group; d.n_inst = g.n_inst;
     d.c_node_in = g.cls_on ? g.c_node_in : nullptr; d.write_obj_cls = a.write_obj_cls;
     return d;

@@ -125,11 +125,11 @@ int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
 int ag_ctx_set_option(ag_ctx* ctx, const char* name, int32_t value);
 int ag_ctx_get_option(ag_ctx* ctx, const char* name, int32_t* out_value);
 
-/* Candidate-forwards of the LAST ag_rollout / ag_rollout_async call on this context: executed (sum over launches of the
- * candidates each model forward was launched over) and needed (sum of action_repeat over the batch).  With the
- * repeat-aware launch order the two are equal; with "repeat_sort" 0 (and for masked batches) every candidate of a launch
- * chunk is stepped to the chunk's maximum, as the reference steps the whole batch to the batch maximum
- * (forward_dynamics.py:156-161). */
+/* Candidate-forwards of the LAST ag_rollout / ag_rollout_async / ag_rollout_actions call on this context: executed (sum over
+ * launches of the candidates each model forward was launched over) and needed (sum of action_repeat over the batch).  With
+ * the repeat-aware launch order (default; masked batches included) the two are equal; with "repeat_sort" 0 every candidate of
+ * a launch chunk is stepped to the chunk's maximum, as the reference steps the whole batch to the batch maximum
+ * (forward_dynamics.py:156-161).  After ag_rollout_actions the call waits for the device (the sums live there). */
 int ag_ctx_rollout_counts(ag_ctx* ctx, int64_t* out_executed, int64_t* out_needed);
 
 /* Replaces construct_edges_from_states_batch (src/dynamics/dataset/graph.py:233-298).

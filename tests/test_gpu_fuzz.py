@@ -101,13 +101,14 @@ def test_random_masked_configurations(seed):
     args = (torch.from_numpy(state).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(act).to(dev))
     ppm = _ppm(task, material)
     base = ag.dynamics_masked(*args, m, dev, ppm)["state_seqs"]
+    assert eng.rollout_counts() == (int(reps[:, 0].sum()), int(reps[:, 0].sum()))      # masked batches too: no surplus forward
     want = O.dynamics_masked(W, 3, state, mask, act, task)["state_seqs"]
     err = np.abs(base.cpu().numpy() - want).reshape(B, -1).max(1)
     assert (err <= POS_TOL).mean() >= 0.9, (seed, material, err)
     eng.set_chunk(int(rng.integers(0, B + 1)))
     try:
         with eng.options(ragged=int(rng.integers(0, 2)), streams=int(rng.integers(1, 3)), latency=int(rng.integers(-1, 2)),
-                         ell_graph=int(rng.integers(0, 2))):
+                         ell_graph=int(rng.integers(0, 2)), repeat_sort=int(rng.integers(0, 2))):
             again = ag.dynamics_masked(*args, m, dev, ppm)["state_seqs"]
     finally:
         eng.set_chunk(0)

@@ -650,6 +650,11 @@ def test_ragged_row_list_equals_dense_rows_bitwise(ag, O, dev, topk):
     a = _actions(state[0], B, 1, [3, 2, 4, 1, 5, 2, 3], rng)[:, 0]
     args = (torch.from_numpy(state).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(a).to(dev))
     ragged = ag.dynamics_masked(*args, m, dev, _ppm(task, "rope"))["state_seqs"]
+    assert m.engine(dev).rollout_counts() == (20, 20)                    # repeats 3+2+4+1+5+2+3: the live prefix shrinks per step
+    with m.engine(dev).options(repeat_sort=0):
+        unsorted = ag.dynamics_masked(*args, m, dev, _ppm(task, "rope"))["state_seqs"]
+        assert m.engine(dev).rollout_counts() == (35, 20)                # every slot stepped to the chunk maximum (5)
+    assert torch.equal(unsorted, ragged)
     with m.engine(dev).options(ragged=0):
         dense = ag.dynamics_masked(*args, m, dev, _ppm(task, "rope"))["state_seqs"]
     assert torch.isfinite(ragged).all() and torch.equal(ragged, dense)
