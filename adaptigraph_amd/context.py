@@ -125,6 +125,13 @@ class Engine:
         self.check(self.lib.ag_ctx_rollout_counts(self._ctx, C.byref(ex), C.byref(need)))
         return ex.value, need.value
 
+    def share_counts(self):
+        """Shared first forward of the last rollout call (ag_ctx_share_counts): (edges of the once-per-call base encode,
+        edge slots served by the shared table, edge slots the candidates encoded themselves at that forward)."""
+        out = (C.c_int64 * 3)()
+        self.check(self.lib.ag_ctx_share_counts(self._ctx, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def set_chunk(self, n):
         self.check(self.lib.ag_ctx_set_chunk(self._ctx, int(n)))
 

@@ -67,6 +67,8 @@ struct ag_ctx {
     char* d_plan = nullptr; size_t plan_cap = 0;      // device-planned rollouts (ag_rollout_actions): decoded tool keypoints,
     int* d_plan_sums = nullptr; int plan_sums_n = 0;  // repeats, launch order and per-step live counts; sums pending a read-back
     int* d_overflow = nullptr;
+    unsigned long long* d_share_stats = nullptr;      // shared first forward: [0] slots served by the base table, [1] slots encoded per candidate
+    const int* d_share_nns = nullptr;                 // edges the base encode ran over (workspace of the last rollout call), or null
     float* d_cself = nullptr;    // (256, NFP): rows 0/1 = C of an object / tool self-loop edge (see GraphBufs)
     // second in-library stream: alternate chunks run on it so that the HBM-bound kernels of one chunk overlap the
     // MFMA-bound chains of the other (fork/join with events around every rollout call)
@@ -85,19 +87,26 @@ struct ag_ctx {
 
 namespace {
 
-struct OptName { const char* name; const char* env; int Options::* field; bool env_negates; };
+struct OptName { const char* name; const char* env; int Options::* field; bool env_negates; int lo, hi; };
 const OptName kOptions[] = {
-    {"streams", "AG_STREAMS", &Options::streams, false},          {"chunk", "AG_CHUNK", &Options::chunk, false},
-    {"latency", "AG_LATENCY", &Options::latency, false},          {"ragged", "AG_NO_RAGGED", &Options::ragged, true},
-    {"ell_graph", "AG_NO_ELL_GRAPH", &Options::ell_graph, true},  {"self_dedupe", "AG_NO_SELF_DEDUPE", &Options::self_dedupe, true},
-    {"repeat_sort", "AG_NO_REPEAT_SORT", &Options::repeat_sort, true},
-    {"edge_wgs", "AG_EDGE_WGS", &Options::edge_wgs, false},       {"edge_block_min", "AG_EDGE_BLOCK_MIN", &Options::edge_block_min, false},
-    {"enc_persist", "AG_ENC_PERSIST", &Options::enc_persist, false}, {"stagger_us", "AG_STAGGER_US", &Options::stagger_us, false},
-    {"device_decode", "AG_DEVICE_DECODE", &Options::device_decode, false}, {"zigzag", "AG_ZIGZAG", &Options::zigzag, false},
+    {"streams", "AG_STREAMS", &Options::streams, false, 0, ag_ctx::kMaxStreams},
+    {"chunk", "AG_CHUNK", &Options::chunk, false, 0, 1 << 20},
+    {"latency", "AG_LATENCY", &Options::latency, false, -1, 1},
+    {"ragged", "AG_NO_RAGGED", &Options::ragged, true, 0, 1},
+    {"ell_graph", "AG_NO_ELL_GRAPH", &Options::ell_graph, true, 0, 1},
+    {"self_dedupe", "AG_NO_SELF_DEDUPE", &Options::self_dedupe, true, 0, 1},
+    {"repeat_sort", "AG_NO_REPEAT_SORT", &Options::repeat_sort, true, 0, 1},
+    {"edge_wgs", "AG_EDGE_WGS", &Options::edge_wgs, false, 1, 1 << 16},
+    {"edge_block_min", "AG_EDGE_BLOCK_MIN", &Options::edge_block_min, false, -1, 0x7fffffff},
+    {"enc_persist", "AG_ENC_PERSIST", &Options::enc_persist, false, 0, 1 << 20},
+    {"stagger_us", "AG_STAGGER_US", &Options::stagger_us, false, 0, 1000},
+    {"device_decode", "AG_DEVICE_DECODE", &Options::device_decode, false, -1, 1},
+    {"zigzag", "AG_ZIGZAG", &Options::zigzag, false, 0, 1},
+    {"share_first", "AG_SHARE_FIRST", &Options::share_first, false, -1, 1},
 };
-void options_from_env(Options& o) {
+void options_from_env(Options& o) {   // values from the environment are clamped into the option's range
     for (const OptName& n : kOptions)
-        if (const char* e = getenv(n.env)) o.*(n.field) = n.env_negates ? (atoi(e) ? 0 : 1) : atoi(e);
+        if (const char* e = getenv(n.env)) o.*(n.field) = n.env_negates ? (atoi(e) ? 0 : 1) : std::min(n.hi, std::max(n.lo, atoi(e)));
 }
 
 int fail(ag_ctx* c, int code, const char* fmt, ...) {
@@ -275,12 +284,14 @@ struct Work {
     int* ell; int* deg; int* slice_tot; int* cta_flag;
     int* recv; int* send; int* row_ptr; int* n_edges;
     int* ns_edge; int* n_ns;
+    int* send_pk;                // first forward of a dynamics() call (GraphBufs::send_pk)
     int* rowlist; int* n_rows;   // ragged batches (GraphBufs::rowlist)
 };
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
 int ensure_slab(ag_ctx* c, size_t bytes) {
+    c->d_share_nns = nullptr;                              // pointed into the workspace that is re-carved now
     if (c->slab.cap >= bytes) { c->slab.used = 0; return AG_OK; }
     if (c->slab.base) HIPCHK(c, hipFree(c->slab.base));
     c->slab.base = nullptr; c->slab.cap = 0;
@@ -297,7 +308,7 @@ size_t work_bytes(int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices
     size_t bytes = 16 * 256;
     bytes += rows * (NODE_IN + F15_PITCH + (own_group ? n_inst : 0)) * 4 + 6 * rows * NFP * 4 + ((size_t)Bc * c_cap + 256) * NFP * 4;
     if (own_edges) bytes += rows * (size_t)(ell_stride + 1) * 4 + (size_t)Bc * (slices + 3) * 4 + 3 * (size_t)Bc * edge_cap * 4 + (size_t)Bc * (N + 1) * 4;
-    if (roll) bytes += rows * 4 + 1024 + (size_t)Bc * 4 + (size_t)Bc * N_HIS_MAX * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
+    if (roll) bytes += (size_t)Bc * edge_cap * 4 + rows * 4 + 1024 + (size_t)Bc * 4 + (size_t)Bc * N_HIS_MAX * N * 3 * 4 + 2 * (size_t)Bc * N_o * 3 * 4 + 2 * rows +
                        (size_t)cls_rows(N_o, N - N_o, Bc) * (NODE_IN + 4 * NFP) * 4;
     return bytes + 64 * 256;
 }
@@ -331,6 +342,7 @@ int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int 
         w.g.recv = w.recv; w.g.send = w.send; w.g.row_ptr = w.row_ptr; w.g.n_edges = w.n_edges;
     }
     if (roll) {
+        w.send_pk = s.take<int>((size_t)Bc * edge_cap);
         w.rowlist = s.take<int>(rows);
         w.n_rows = s.take<int>((size_t)Bc + 64);            // ragged batches: row count per number of live slots (k_build_rowlist)
         w.r.hist = s.take<float>((size_t)Bc * N_HIS_MAX * N * 3);   // (Bc, n_his, N, 3) with the model's n_his (4 or 5)
@@ -381,24 +393,36 @@ int auto_chunk(const ag_ctx* c, int B, int N) {
     return (int)std::max(1L, std::min<long>(bc, B));
 }
 
+// Small launches are latency-bound: below one chip-filling round of 128-row workgroups the latency-mode chains take over
+// (ag_lat.hip: 32-row workgroups, every layer split over the four wavefronts; bit-identical results).  Options::latency:
+// 0 never, 1 always, -1 = by size.  (Thresholds in 128-row workgroups of the throughput kernels: a latency workgroup reads
+// its weight fragments from L2 itself - 200 KB per layer - so beyond about one latency workgroup per CU the L2 traffic eats
+// the gain: rope 64 x 301 rows = 151 workgroups runs the same 71 us either way, one rope graph 66 -> 31 us.)
+bool lat_available(const ag_ctx* c, const GraphBufs& g) { return c->d_wlat && !g.wb3 && g.n_his != 5; }
+bool lat_edge_for(const ag_ctx* c, const GraphBufs& g) {
+    const long edge_wgs = (long)g.B * g.c_cap / 128;
+    return lat_available(c, g) && (c->opt.latency >= 0 ? c->opt.latency == 1 : edge_wgs <= 128);
+}
+bool lat_node_for(const ag_ctx* c, const GraphBufs& g) {
+    const long node_wgs = ((long)g.B * g.N + 127) / 128;
+    return lat_available(c, g) && (c->opt.latency >= 0 ? c->opt.latency == 1 : node_wgs <= 64);
+}
+// relation encoder + W1 over the graph's (non-self-loop) edges -> C
+int run_edge_chain(ag_ctx* c, const GraphBufs& g, hipStream_t st) {
+    Scoped p(c, FAM_EDGE_ENC);
+    if (lat_edge_for(c, g)) HIPCHK(c, launch_edge_enc_lat(c->d_wlat, g, st));
+    else HIPCHK(c, launch_edge_enc(c->d_w, g, st));
+    return AG_OK;
+}
+
 // one model forward on a prepared workspace (node_in, feat12, group, edges all set).  With g.cls_on the particle
 // encoder outputs already sit in the class table (encoded at look-ahead-step start) and k_node_enc is skipped.
 int run_model(ag_ctx* c, const GraphBufs& g, float* pred_pos, float* pred_motion, hipStream_t st) {
     if (!g.cls_on) { Scoped p(c, FAM_NODE_ENC); HIPCHK(c, launch_node_enc(c->d_w, g, 0, (long)g.B * g.N, st)); }
-    // Small launches are latency-bound: below one chip-filling round of 128-row workgroups the latency-mode chains take
-    // over (ag_lat.hip: 32-row workgroups, every layer split over the four wavefronts; bit-identical results).
-    // Options::latency: 0 never, 1 always, -1 = by size.
-    const int lat_env = c->opt.latency;
-    const bool lat_ok = c->d_wlat && !g.wb3 && g.n_his != 5;
-    const long edge_wgs = (long)g.B * g.c_cap / 128, node_wgs = ((long)g.B * g.N + 127) / 128;
-    // (thresholds in 128-row workgroups of the throughput kernels: a latency workgroup reads its weight fragments from L2
-    // itself - 200 KB per layer - so beyond about one latency workgroup per CU the L2 traffic eats the gain: rope 64 x 301
-    // rows = 151 workgroups runs the same 71 us either way, one rope graph 66 -> 31 us)
-    const bool lat_edge = lat_ok && (lat_env >= 0 ? lat_env == 1 : edge_wgs <= 128);
-    const bool lat_node = lat_ok && (lat_env >= 0 ? lat_env == 1 : node_wgs <= 64);
-    { Scoped p(c, FAM_EDGE_ENC);
-      if (lat_edge) HIPCHK(c, launch_edge_enc_lat(c->d_wlat, g, st));
-      else HIPCHK(c, launch_edge_enc(c->d_w, g, st)); }
+    const bool lat_node = lat_node_for(c, g);
+    if (g.send_pk && lat_node) return fail(c, AG_ERR_INVALID, "internal: shared first forward on the latency-mode chains");
+    int rc = run_edge_chain(c, g, st);
+    if (rc) return rc;
     for (int ps = 0; ps < c->dims.pstep; ++ps) {
         const bool last = ps + 1 == c->dims.pstep;
         Scoped p(c, last ? FAM_NODE_FINAL : FAM_NODE_PROP);
@@ -470,6 +494,8 @@ int ag_ctx_create(int32_t device_id, const ag_dims* dims, ag_ctx** out) {
     HIPCHK(c, hipSetDevice(device_id));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_w), (size_t)WeightLayout::TOTAL * 4));
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_overflow), 256));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_share_stats), 256));
+    HIPCHK(c, hipMemset(c->d_share_stats, 0, 256));
 #ifdef AG_DIAG
     c->diag = diag_create();
 #endif
@@ -493,6 +519,7 @@ int ag_ctx_destroy(ag_ctx* c) {
     if (c->d_wb3) (void)hipFree(c->d_wb3);
     if (c->d_wlat) (void)hipFree(c->d_wlat);
     if (c->d_overflow) (void)hipFree(c->d_overflow);
+    if (c->d_share_stats) (void)hipFree(c->d_share_stats);
     if (c->d_cself) (void)hipFree(c->d_cself);
     if (c->d_repeat) (void)hipFree(c->d_repeat);
     if (c->d_plan) (void)hipFree(c->d_plan);
@@ -519,7 +546,12 @@ int ag_ctx_set_chunk(ag_ctx* c, int32_t n) {
 int ag_ctx_set_option(ag_ctx* c, const char* name, int32_t value) {
     if (!c || !name) return AG_ERR_INVALID;
     for (const OptName& n : kOptions)
-        if (!strcmp(name, n.name)) { c->opt.*(n.field) = value; return AG_OK; }
+        if (!strcmp(name, n.name)) {
+            if (value < n.lo || value > n.hi)
+                return fail(c, AG_ERR_INVALID, "option '%s' = %d is outside [%d, %d]", name, value, n.lo, n.hi);
+            c->opt.*(n.field) = value;
+            return AG_OK;
+        }
     return fail(c, AG_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -542,6 +574,18 @@ int ag_ctx_rollout_counts(ag_ctx* c, int64_t* out_executed, int64_t* out_needed)
         c->d_plan_sums = nullptr;
     }
     *out_executed = c->fwd_executed; *out_needed = c->fwd_needed;
+    return AG_OK;
+}
+
+int ag_ctx_share_counts(ag_ctx* c, int64_t* out3) {
+    if (!c || !out3) return AG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    unsigned long long h[2] = {0, 0};
+    int nns = 0;
+    HIPCHK(c, hipMemcpy(h, c->d_share_stats, sizeof h, hipMemcpyDeviceToHost));
+    if (c->d_share_nns) HIPCHK(c, hipMemcpy(&nns, c->d_share_nns, 4, hipMemcpyDeviceToHost));
+    out3[0] = nns; out3[1] = (int64_t)h[0]; out3[2] = (int64_t)h[1];
     return AG_OK;
 }
 
@@ -894,13 +938,65 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         c->fwd_executed = -1; c->fwd_needed = -1;
     }
 
+    // Shared first forward (Options::share_first).  dynamics() broadcasts ONE start state to all candidates with a constant
+    // history (forward_dynamics.py:25), then builds and encodes every candidate's graph separately (:125, model.py:303).  At
+    // that forward the relation input of an object-object edge - attrs, group difference, position / residual differences
+    // (model.py:249-282) - does not depend on the candidate, so neither does its C row; and the object senders a candidate's
+    // receiver keeps are a subset of what it keeps in the start state's graph WITHOUT the tool (a tool can only push senders
+    // out of a row's top-k).  So: build that base graph once per call, run the edge chain once over its non-self edges into
+    // a shared table, and let the first forward's message passing take the C row of every slot found in the base row from
+    // there (k_ell_index: send_pk); per candidate only the edges with a tool at either end are encoded.  Bit-identical: a
+    // row's chain does not depend on the lane / workgroup / launch that computes it.
+    const int kb = std::min(p->N_o, p->topk);
+    bool share = c->opt.share_first != 0 && p->y_mode == 0 && !d_obj_mask && ell_full && p->topk < p->N_o && k <= 255;
+    if (c->opt.share_first < 0 && p->B < 8) share = false;   // a handful of candidates: the base build costs more than it saves
+    {   // launches small enough for the latency-mode propagate chains (ag_lat.hip) keep their own C rows
+        GraphBufs gt{};
+        gt.B = std::min(Bc, p->B); gt.N = N; gt.n_his = n_his; gt.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
+        if (lat_node_for(c, gt)) share = false;
+    }
+    const int base_cap = (int)round_up((size_t)p->N_o * kb, 256);
+    const int base_slices = pick_slices(c, 1, p->N_o);
+    const size_t base_bytes = !share ? 0 : (size_t)base_cap * (NFP + 3) * 4 + (size_t)p->N_o * (NODE_IN + F15_PITCH + 2) * 4 +
+                                           2 * (size_t)p->N_o + (size_t)(base_slices + 8) * 4 + 24 * 256;
     const size_t wb = work_bytes(Ba, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
-    rc = ensure_slab(c, wb * ns);
+    rc = ensure_slab(c, wb * ns + base_bytes);
     if (rc) return rc;
     Work ws[ag_ctx::kMaxStreams] = {};
     for (int i = 0; i < ns; ++i) {
         rc = carve_work(c, ws[i], Ba, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
         if (rc) return rc;
+    }
+    const int* base_send = nullptr; const int* base_deg = nullptr; const float* C_share = nullptr;
+    HIPCHK(c, hipMemsetAsync(c->d_share_stats, 0, 16, st));   // counters of this call (ag_ctx_share_counts)
+    if (share) {
+        Slab& sl = c->slab;
+        float* b_C = sl.take<float>((size_t)base_cap * NFP);
+        int* b_send = sl.take<int>(base_cap); int* b_recv = sl.take<int>(base_cap); int* b_ns = sl.take<int>(base_cap);
+        float* b_node_in = sl.take<float>((size_t)p->N_o * NODE_IN);
+        float* b_feat = sl.take<float>((size_t)p->N_o * F15_PITCH);
+        float* b_group = sl.take<float>(p->N_o);
+        int* b_deg = sl.take<int>(p->N_o);
+        uint8_t* b_mask = sl.take<uint8_t>(p->N_o); uint8_t* b_tool = sl.take<uint8_t>(p->N_o);
+        int* b_slice_tot = sl.take<int>(base_slices); int* b_cta = sl.take<int>(1);
+        int* b_n_edges = sl.take<int>(1); int* b_n_ns = sl.take<int>(1);
+        if (sl.used > sl.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
+        HIPCHK(c, launch_share_prep(d_state0, p->N_o, n_his, b_node_in, b_feat, b_group, b_mask, b_tool, st));
+        EdgeArgs be{};
+        be.pos = d_state0; be.pos_bstride = (long)p->N_o * 3; be.mask = b_mask; be.tool = b_tool; be.thr = p->adj_thresh;
+        be.B = 1; be.N = p->N_o; be.topk = p->topk; be.cta = 0; be.edge_cap = base_cap; be.slices = base_slices;
+        be.ell_full = 1; be.ell = b_send; be.ell_stride = kb; be.ell_bstride = base_cap; be.deg = b_deg;
+        be.slice_tot = b_slice_tot; be.cta_flag = b_cta; be.recv = b_recv; be.send = b_send; be.n_edges = b_n_edges;
+        be.ns_edge = b_ns; be.n_ns = b_n_ns; be.max_nR = 0x7fffffff; be.block_min_rows = c->opt.edge_block_min;
+        HIPCHK(c, launch_edge_build(be, st, prof_mark, c));
+        GraphBufs gb{};
+        gb.node_in = b_node_in; gb.feat12 = b_feat; gb.group = b_group; gb.C = b_C; gb.recv = b_recv; gb.send = b_send;
+        gb.n_edges = b_n_edges; gb.ns_edge = b_ns; gb.n_ns = b_n_ns; gb.B = 1; gb.N = p->N_o; gb.n_p = p->N_o; gb.n_inst = 1;
+        gb.edge_cap = base_cap; gb.c_cap = base_cap; gb.n_his = n_his; gb.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
+        gb.diag = c->diag;
+        rc = run_edge_chain(c, gb, st);
+        if (rc) return rc;
+        base_send = b_send; base_deg = b_deg; C_share = b_C; c->d_share_nns = b_n_ns;
     }
     hipStream_t streams[ag_ctx::kMaxStreams] = {st, st, st, st};
     if (ns > 1) {
@@ -990,6 +1086,13 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
                     if (ragged) g.n_rows = w.n_rows + n_live;   // rows of the live slots (+ the phantom candidate's)
                 }
                 ea.B = n_live; g.B = n_live; ra.B = n_live;
+                // the call's first forward (start state, constant history): object-object C rows from the shared table
+                const bool share_step = share && li == 0 && ai == 1 && !lat_node_for(c, g);
+                ea.send_pk = share_step ? w.send_pk : nullptr; g.send_pk = ea.send_pk;
+                if (share_step) {
+                    ea.base_send = base_send; ea.base_deg = base_deg; ea.base_stride = kb; ea.share_No = p->N_o;
+                    ea.share_stats = c->d_share_stats; g.C_share = C_share; g.share_kb = kb;
+                }
                 HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));
                 if (g.ns_edge && !ell_full) { Scoped s(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, n_live, N, edge_cap, w.ns_edge, w.n_ns, ea.live, cs)); }
                 rc = run_model(c, g, w.r.pred, w.r.motion, cs);

@@ -65,7 +65,9 @@ enum Family { FAM_EDGE_COUNT = 0, FAM_EDGE_EMIT, FAM_PREP, FAM_NODE_ENC, FAM_EDG
               FAM_NODE_FINAL, FAM_ROLL_INIT, FAM_ROLL_UPDATE, FAM_COST, FAM_COUNT };
 
 // ---- per-context tuning / A-B switches.  Defaults come from the environment ONCE, at ag_ctx_create (the AG_* name in
-// brackets); ag_ctx_set_option changes them per context afterwards.  None of them changes a result (bit-identical paths).
+// brackets); ag_ctx_set_option changes them per context afterwards.  None of them changes a result (bit-identical paths),
+// with ONE exception: device_decode (see there).  Every option has a valid range (kOptions in ag_api.hip): ag_ctx_set_option
+// refuses a value outside it, values from the environment are clamped into it.
 struct Options {
     int streams = 0;          // [AG_STREAMS]        in-library streams of a rollout: 0 = by batch size, else 1..4
     int chunk = 0;            // [AG_CHUNK]          candidates per launch chunk: 0 = automatic (ag_ctx_set_chunk overrides)
@@ -83,7 +85,12 @@ struct Options {
                               //                     (one stream: k_node_prop 170.5 -> 168.3, final round 83.4 -> 81.4 ms per rollout;
                               //                     four streams: 477.3 -> 475.8 ms - the other chunks' traffic evicts most of it)
     int device_decode = -1;   // [AG_DEVICE_DECODE]  consumed by the Python shim: dynamics() hands GPU-resident actions to
-                              //                     ag_rollout_actions (-1: when the task config bounds the repeat, 0 never, 1 always)
+                              //                     ag_rollout_actions (-1: when the task config bounds the repeat, 0 never, 1 always).
+                              //                     The one switch that is NOT bit-neutral: cos/sin of the decode are then the device's,
+                              //                     so action_seqs agrees with a host decode to ~1e-7, not bit for bit
+    int share_first = -1;     // [AG_SHARE_FIRST]    first forward of a dynamics() call: the relation encoder runs ONCE over the
+                              //                     object-object edges of the start state's tool-free graph and every candidate reads
+                              //                     those C rows (-1: batches of 8 candidates or more, 0 never, 1 whenever possible)
 };
 
 // ---- launchers (defined in the .hip files) ------------------------------------------------------------
@@ -116,6 +123,13 @@ struct EdgeArgs {
     int block_min_rows;         // Options::edge_block_min (-1: built-in threshold)
     const int* live;            // null, or device int: candidates [*live, B) of this launch have no forward left (device-planned
                                 // rollout, RollPlan): their workgroups exit and their graphs are presented as empty
+    // First forward of a dynamics() call (GraphBufs::send_pk): k_ell_index looks every object-object slot up in the BASE graph
+    // (the start state's graph without the tool: base_send / base_deg, base_stride slots per row) and writes, per slot,
+    // send_pk = sender | (position in the base row + 1) << 12 (0 in the upper bits: not in the base row); slots found there are
+    // left out of ns_edge - their C row is the base table's.  share_stats (device, 2 x uint64, may be null): += slots served by
+    // the base table, += slots this candidate encodes itself.
+    int* send_pk; const int* base_send; const int* base_deg; int base_stride; int share_No;
+    unsigned long long* share_stats;
 };
 hipError_t launch_edge_build(const EdgeArgs& a, hipStream_t st, void (*mark)(void*, int, int), void* mark_ctx);
 // list of non-self-loop edges per candidate (self-loop dedupe, see GraphBufs)
@@ -173,6 +187,12 @@ struct GraphBufs {
     // particle index) is computed ONCE, on the rows of a phantom candidate B (all particles masked out, no tools, no
     // edges) appended to the list; k_roll_update applies it to the masked-out rows of every real candidate.
     const int* rowlist; const int* n_rows; // (B*N + N_o,), device int; null = all rows
+    // ---- first forward of a dynamics() call (forward_dynamics.py:25: ONE start state broadcast to all candidates, constant
+    // history).  The relation input of an object-object edge is then the same in every candidate, so its C row is too: it is
+    // encoded once per call into C_share (row = receiver * share_kb + position in the receiver's row of the tool-free base
+    // graph), and the message passing of that forward reads send_pk (EdgeArgs) instead of send: sender in the low 12 bits,
+    // position + 1 above them when the slot's C row is the base table's.  Null: every candidate's own C rows (all other forwards).
+    const int* send_pk; const float* C_share; int share_kb;
     int n_his;                             // 4 (0 = 4), or 5 on the forward path (feature rows then have pitch F15_PITCH)
     int enc_persist, stagger_us, zigzag;   // Options of the owning context
     void* diag;                            // diagnostic build (-DAG_DIAG, ag_diag.hip) only: the context's probe state, else null
@@ -256,6 +276,9 @@ hipError_t launch_roll_plan(const RollPlan& p, hipStream_t st);
 // also clears the phantom candidate's mask and degree rows
 hipError_t launch_build_rowlist(const uint8_t* obj_mask, const int* cand, int b0, int B, int N_o, int M, int* rowlist, int* tab,
                                 uint8_t* mask, int* deg, hipStream_t st);
+// inputs of the shared first-forward edge encode (GraphBufs::C_share): the object rows of look-ahead step 0, as k_roll_init writes them
+hipError_t launch_share_prep(const float* state0, int N_o, int n_his, float* node_in, float* feat, float* group, uint8_t* mask,
+                             uint8_t* tool, hipStream_t st);
 hipError_t launch_roll_init(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);
 hipError_t launch_roll_update(const RollArgs& a, const RollBufs& r, const GraphBufs& g, hipStream_t st);
 

@@ -54,6 +54,8 @@ struct EdgeDev {
     int* recv; int* send; int* row_ptr; int* n_edges; int* overflow; int max_nR; int zero_on_overflow;
     int block_min_rows;                  // slices with at least this many rows take the 64-rows-per-wavefront path
     const int* live;                     // see EdgeArgs
+    int* send_pk; const int* base_send; const int* base_deg; int base_stride, share_No;   // see EdgeArgs (first forward)
+    unsigned long long* share_stats;
 };
 
 __device__ __forceinline__ float dist_exact(float xi, float yi, float zi, float xj, float yj, float zj) {
@@ -673,11 +675,13 @@ __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
 // through the relation encoder), edge counts.  Integer scan, slot order = (receiver, position in row) = CSR order.
 __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
     __shared__ int scan[EW];
+    __shared__ int n_shared;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (a.live && b >= *a.live) {                           // no forward left: nothing for the relation encoder to do
         if (tid == 0) { a.n_ns[b] = 0; a.n_edges[b] = 0; }
         return;
     }
+    if (tid == 0) n_shared = 0;
     int total = 0;
     for (int s = 0; s < a.slices; ++s) total += a.slice_tot[b * a.slices + s];
     const bool hide = total > a.max_nR && a.zero_on_overflow;   // downstream kernels then see an empty graph
@@ -685,13 +689,32 @@ __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
     const int* ell = a.ell + (long)b * a.ell_bstride;
     int* recv = a.recv + (long)b * a.edge_cap;
     int* ns = a.ns_edge + (long)b * a.edge_cap;
+    // First forward of a dynamics() call (EdgeArgs::send_pk): an object-object slot whose sender is in the receiver's row of
+    // the base graph takes its C row from the shared table and is left out of the relation encoder's list.  (With the same
+    // positions every object sender a candidate keeps IS in the base row - a tool can only push senders out of a row's top-k -
+    // but nothing relies on it: a sender that is not found is simply encoded by the candidate itself.)
+    int* pk = a.send_pk ? a.send_pk + (long)b * a.edge_cap : nullptr;
     const int per = (a.N + EW - 1) / EW;
     const int i0 = min(a.N, tid * per), i1 = min(a.N, i0 + per);
-    int mine = 0;
+    int mine = 0, shared = 0;
     for (int i = i0; i < i1; ++i) {
         if (hide) deg[i] = 0;
         const int d = deg[i];
-        for (int t = 0; t < d; ++t) mine += ell[(long)i * a.ell_stride + t] != i ? 1 : 0;
+        const int bd = (pk && i < a.share_No) ? a.base_deg[i] : 0;
+        const int* brow = a.base_send + (long)i * a.base_stride;
+        for (int t = 0; t < d; ++t) {
+            const int e = i * a.ell_stride + t;
+            const int j = ell[e];
+            int own = j != i ? 1 : 0;
+            if (pk) {
+                int v = j;
+                if (own && j < a.share_No)
+                    for (int u = 0; u < bd; ++u)
+                        if (brow[u] == j) { v = j | ((u + 1) << 12); own = 0; ++shared; break; }
+                pk[e] = v;
+            }
+            mine += own;
+        }
     }
     scan[tid] = mine;
     __syncthreads();
@@ -708,13 +731,22 @@ __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
         for (int t = 0; t < d; ++t) {
             const int e = i * a.ell_stride + t;
             recv[e] = i;
-            if (ell[e] != i) ns[pos++] = e;
+            const bool own = pk ? (ell[e] != i && (pk[e] >> 12) == 0) : ell[e] != i;   // pk[e]: written above by this thread
+            if (own) ns[pos++] = e;
         }
+    }
+    if (pk && a.share_stats) {
+        if (shared) atomicAdd(&n_shared, shared);
+        __syncthreads();
     }
     if (tid == EW - 1) {
         a.n_ns[b] = scan[EW - 1];
         a.n_edges[b] = hide ? 0 : total;
         if (a.overflow && total > a.max_nR) atomicMax(a.overflow, total);
+        if (pk && a.share_stats) {                           // integer counters: order-free
+            atomicAdd(a.share_stats + 0, (unsigned long long)n_shared);
+            atomicAdd(a.share_stats + 1, (unsigned long long)scan[EW - 1]);
+        }
     }
 }
 
@@ -731,6 +763,8 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     a.ns_edge = h.ns_edge; a.n_ns = h.n_ns;
     a.recv = h.recv; a.send = h.send; a.row_ptr = h.row_ptr; a.n_edges = h.n_edges; a.overflow = h.overflow;
     a.max_nR = h.max_nR; a.zero_on_overflow = h.zero_on_overflow; a.live = h.live;
+    a.send_pk = a.ell_full ? h.send_pk : nullptr; a.base_send = h.base_send; a.base_deg = h.base_deg; a.base_stride = h.base_stride;
+    a.share_No = h.share_No; a.share_stats = h.share_stats;
     a.block_min_rows = h.block_min_rows >= 0 ? h.block_min_rows : BLOCK_MIN_ROWS;   // A/B switch (Options::edge_block_min); results identical
     const size_t lds = edge_lds_bytes(h.N);
     // the > 64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: track it per device ordinal

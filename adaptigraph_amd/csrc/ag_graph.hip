@@ -399,6 +399,30 @@ hipError_t launch_roll_plan(const RollPlan& p, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ shared first forward
+// Inputs of the once-per-call edge encode (GraphBufs::C_share): what k_roll_init<NH> writes for the OBJECT rows of every
+// candidate at look-ahead step 0 (forward_dynamics.py:25: one start state, n_his equal frames) - attrs (1,0), group 1,
+// residuals exactly 0, current position = the start state - for the N_o object particles alone, all valid, no tool.
+__global__ void k_share_prep(const float* __restrict__ state0, int N_o, int fp, int cur_off, float* __restrict__ node_in,
+                             float* __restrict__ feat, float* __restrict__ group, uint8_t* __restrict__ mask,
+                             uint8_t* __restrict__ tool) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N_o) return;
+    float* n = node_in + (long)i * NODE_IN;
+    n[0] = 1.0f; n[1] = 0.0f; n[2] = 0.0f; n[3] = 0.0f; n[4] = 0.0f; n[5] = 0.0f; n[6] = 1.0f; n[7] = 0.0f;   // the edge chain reads [0], [1]
+    float* f = feat + (long)i * fp;
+    for (int c = 0; c < fp; ++c) f[c] = 0.0f;
+    f[cur_off] = state0[3 * i]; f[cur_off + 1] = state0[3 * i + 1]; f[cur_off + 2] = state0[3 * i + 2];
+    group[i] = 1.0f;
+    mask[i] = 1; tool[i] = 0;
+}
+hipError_t launch_share_prep(const float* state0, int N_o, int n_his, float* node_in, float* feat, float* group, uint8_t* mask,
+                             uint8_t* tool, hipStream_t st) {
+    hipLaunchKernelGGL(k_share_prep, dim3((unsigned)((N_o + 255) / 256)), dim3(256), 0, st, state0, N_o, feat_pitch(n_his),
+                       3 * (n_his - 1), node_in, feat, group, mask, tool);
+    return hipGetLastError();
+}
+
 static RollDev to_dev(const RollArgs& a, const RollBufs& r, const GraphBufs& g) {
     RollDev d;
     d.a = a; d.hist = r.hist; d.pred = r.pred; d.mask = r.mask; d.tool = r.tool;

@@ -286,6 +286,9 @@ struct GDev {
     // particles and tools, plus one phantom candidate that stands for every masked-out particle (GraphBufs) - instead of
     // all B*N rows; rowlist[slot] = dense row b*N + i, *n_rows = number of slots.  Null: every dense row, in order.
     const int* rowlist; const int* n_rows;
+    // first forward of a dynamics() call (GraphBufs::send_pk): `send` then holds sender | (position + 1) << 12, and a slot with
+    // non-zero upper bits takes its C row from the shared base table (row = receiver * share_kb + position)
+    const float* C_share; unsigned share_kb;
     int f_pitch, cur_off;                     // feature-row pitch and offset of the current position in it (n_his 4: 12, 9)
 #ifdef AG_DIAG
     unsigned long long* dbg;   // diagnostic build (ag_diag.hip) only: stamps per workgroup, never read by kernels
@@ -321,11 +324,14 @@ struct PassRow {
     int i, deg, b, e0;       // particle, in-degree, candidate, first edge slot; everything else is re-derived per use
 };
 // issue the 10 loads of edge k of the lane's row (C row + V row, five 128-B tiles each, this lane's 16-B piece);
-// sj = the edge's sender
-__device__ __forceinline__ void gather_issue(const GDev& g, const PassRow& r, bool cls, int k, int sj, EdgeBuf& buf,
+// sjp = the edge's sender; SHARE (first forward of a dynamics() call): sender in the low 12 bits, above them position + 1
+// in the receiver's row of the base graph when the C row is the shared table's (GraphBufs::send_pk)
+template <bool SHARE>
+__device__ __forceinline__ void gather_issue(const GDev& g, const PassRow& r, bool cls, int k, int sjp, EdgeBuf& buf,
                                              const float* __restrict__ C, const float* __restrict__ V, int lane) {
     const unsigned c4 = 4u * (lane & 7);
     const bool on = k < r.deg;
+    const int sj = SHARE ? (sjp & 0xfff) : sjp;
     // lanes whose row has no edge k read the self-loop constant row and their own V row: valid addresses, values unused.
     // Class-table rows (first round of a rollout step): a particle that takes part in an edge is valid by construction
     // (masked pairs never pass the radius test, graph.py:253-256), so its row is a pure function of its index.
@@ -334,6 +340,11 @@ __device__ __forceinline__ void gather_issue(const GDev& g, const PassRow& r, bo
     const unsigned tool0 = (unsigned)g.N_o + (unsigned)r.b * g.M;            // + particle index (>= N_o) = class row
     const unsigned vrow = cls ? (sj >= g.N_o ? tool0 + (unsigned)sj : (unsigned)sj) : (unsigned)r.b * (unsigned)g.N + (unsigned)sj;
     const float* cp = C + crow * (unsigned)NFP + c4;
+    if (SHARE) {   // same bits as the candidate's own row would hold: a row's chain does not depend on where it is computed
+        const unsigned sp = (unsigned)sjp >> 12;
+        const float* sh = g.C_share + ((unsigned)r.i * g.share_kb + (sp - 1u)) * (unsigned)NFP + c4;
+        cp = (on && sp != 0u) ? sh : cp;
+    }
     const float* vp = V + vrow * (unsigned)NFP + c4;
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
@@ -358,6 +369,7 @@ __device__ __forceinline__ int wave_max(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+template <bool SHARE>
 __device__ __forceinline__ void gather_agg(const GDev& g, float* stg, long wave_row0, long nrows, Act& x, int lane) {
     const int rr = lane >> 3, c = lane & 7, j = lane & 31, h = lane >> 5;
     const bool cls = g.cls_on && g.first_round;
@@ -442,7 +454,7 @@ __device__ __forceinline__ void gather_agg(const GDev& g, float* stg, long wave_
     PassRow r = row_of(0);
     int idx0 = pidx0[0];
     issue_u(r, u);
-    if (pkmax[0] > 0) gather_issue(g, r, cls, 0, __shfl(idx0, lane & 56, 64), A, C, V, lane);
+    if (pkmax[0] > 0) gather_issue<SHARE>(g, r, cls, 0, __shfl(idx0, lane & 56, 64), A, C, V, lane);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int kmax = pkmax[p], kfast = min(kmax, KFAST);
@@ -466,25 +478,25 @@ __device__ __forceinline__ void gather_agg(const GDev& g, float* stg, long wave_
         for (int t = 0; t < 5; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         int k = 0;
         for (; k + 2 < kfast; k += 2) {
-            gather_issue(g, r, cls, k + 1, sender(k + 1), B, C, V, lane);
+            gather_issue<SHARE>(g, r, cls, k + 1, sender(k + 1), B, C, V, lane);
             gather_consume(A, u, acc, k < r.deg);
-            gather_issue(g, r, cls, k + 2, sender(k + 2), A, C, V, lane);
+            gather_issue<SHARE>(g, r, cls, k + 2, sender(k + 2), A, C, V, lane);
             gather_consume(B, u, acc, k + 1 < r.deg);
         }
         const int left = kfast - k;                                            // 0 (no edge at all), 1 or 2
-        if (left == 2) gather_issue(g, r, cls, k + 1, sender(k + 1), B, C, V, lane);
+        if (left == 2) gather_issue<SHARE>(g, r, cls, k + 1, sender(k + 1), B, C, V, lane);
         if (left >= 1) gather_consume(A, u, acc, k < r.deg);
         if (left == 2) gather_consume(B, u, acc, k + 1 < r.deg);
         for (k = KFAST; k < kmax; ++k) {                                       // rows beyond 32 edges: plain loop
             const int sj = k < r.deg ? snd[k] : r.i;
-            gather_issue(g, r, cls, k, sj, A, C, V, lane);
+            gather_issue<SHARE>(g, r, cls, k, sj, A, C, V, lane);
             gather_consume(A, u, acc, k < r.deg);
         }
         if (p + 1 < 4) {                                                       // next pass: U row and first edge
             r = row_of(p + 1);
             idx0 = pidx0[p + 1];
             issue_u(r, u);
-            if (pkmax[p + 1] > 0) gather_issue(g, r, cls, 0, __shfl(idx0, lane & 56, 64), A, C, V, lane);
+            if (pkmax[p + 1] > 0) gather_issue<SHARE>(g, r, cls, 0, __shfl(idx0, lane & 56, 64), A, C, V, lane);
         }
         float* wp = stg + rr * STG_ROW_PITCH + 4 * c;
 #pragma unroll
@@ -653,7 +665,7 @@ __global__ __launch_bounds__(WG, 2) void k_node_enc(GDev g) {
 // eff <- ReLU(Wb*agg + P + eff)   (model.py:328-330; P carries Wa*p_enc + b_pp)
 //   not last: U = W2*eff, V = W3*eff for the next round (model.py:312-318)
 //   last:     motion = ParticlePredictor(eff) (model.py:44-61, 335); pred = cur + clamp(motion) (model.py:338)
-template <bool LAST>
+template <bool LAST, bool SHARE>
 __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     __shared__ __attribute__((aligned(16))) float lds[CHAIN_LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -680,7 +692,7 @@ __global__ __launch_bounds__(WG, 2) void k_node_prop(GDev g) {
     Act x, y;
     // The residual terms seed the accumulator: y = P + eff, then y += Wb*agg.  All three row loads are issued here,
     // together, instead of two of them stalling the chain after the Wb layer.
-    gather_agg(g, stg, (long)bid * WG_ROWS + wave * 32, nrows, x, lane);
+    gather_agg<SHARE>(g, stg, (long)bid * WG_ROWS + wave * 32, nrows, x, lane);
     __builtin_amdgcn_sched_barrier(0);                       // nothing of what follows is worth a register during the gather
 #ifdef AG_DIAG
     if (g.dbg && tid == 0) g.dbg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -982,7 +994,7 @@ __global__ __launch_bounds__(WGB, 2) void k_node_enc_b3(GDev g) {
     store_rows(x, g.V, row, lane, valid);
 }
 
-template <bool LAST>
+template <bool LAST, bool SHARE>
 __global__ __launch_bounds__(WGB, 2) void k_node_prop_b3(GDev g) {
     __shared__ __attribute__((aligned(16))) float lds[NSLOT * UNIT_FLOATS];
     constexpr int KIND = LAST ? 3 : 2;
@@ -996,7 +1008,7 @@ __global__ __launch_bounds__(WGB, 2) void k_node_prop_b3(GDev g) {
     const float* W = g.wb3;
     Act x, y;
     // fused message passing: the weight ring is not live yet, its first bytes serve as the per-wave staging areas
-    gather_agg(g, lds + wave * STG_FLOATS, (long)blockIdx.x * WGB_ROWS + wave * 32, nrows, x, lane);
+    gather_agg<SHARE>(g, lds + wave * STG_FLOATS, (long)blockIdx.x * WGB_ROWS + wave * 32, nrows, x, lane);
     __syncthreads();
     stream_begin<KIND>(lds, W, tid);
     const int pb = (int)(rowc / g.N), pi = (int)(rowc - (long)pb * g.N);
@@ -1067,6 +1079,7 @@ static GDev to_dev(const float* w, const GraphBufs& g) {
     d.Uin = nullptr; d.Vin = nullptr; d.deg = g.deg; d.ell_stride = g.ell_stride; d.dedupe = g.c_self ? 1 : 0;
     d.self_row = (unsigned)g.self_row; d.n_guard = g.n_guard;
     d.rowlist = g.rowlist; d.n_rows = g.n_rows;
+    d.C_share = nullptr; d.share_kb = 0;
     d.f_pitch = feat_pitch(g.n_his); d.cur_off = g.n_his == 5 ? 12 : 9;
     // Options::stagger_us: offset between the two workgroups of a CU in the fused propagate chains.  Off by default: it removes
     // the "both computing / both gathering" states (probe: 8 % -> 0 % of CU time) but the kernel time moves by <= 1 %
@@ -1125,6 +1138,7 @@ static void set_round(GDev& d, const GraphBufs& g, int round) {
     d.Vin = cls ? g.c_V : g.UV[(round - 1) & 1][1];
     d.U = g.UV[round & 1][0]; d.V = g.UV[round & 1][1];
     d.reverse = g.zigzag ? (round & 1) : 0;
+    if (g.send_pk) { d.send = g.send_pk; d.C_share = g.C_share; d.share_kb = (unsigned)g.share_kb; }   // the message passing only
 }
 hipError_t launch_node_prop(const float* w, const GraphBufs& g, int round, hipStream_t st) {
     GDev d = to_dev(w, g);
@@ -1133,8 +1147,11 @@ hipError_t launch_node_prop(const float* w, const GraphBufs& g, int round, hipSt
 #ifdef AG_DIAG
     if (!d.wb3) d.dbg = diag_node_begin(g.diag, nwg, st);
 #endif
-    if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<false>, dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
-    else hipLaunchKernelGGL(k_node_prop<false>, dim3(nwg), dim3(WG), 0, st, d);
+    if (d.wb3) {
+        if (d.C_share) hipLaunchKernelGGL((k_node_prop_b3<false, true>), dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
+        else hipLaunchKernelGGL((k_node_prop_b3<false, false>), dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
+    } else if (d.C_share) hipLaunchKernelGGL((k_node_prop<false, true>), dim3(nwg), dim3(WG), 0, st, d);
+    else hipLaunchKernelGGL((k_node_prop<false, false>), dim3(nwg), dim3(WG), 0, st, d);
 #ifdef AG_DIAG
     if (d.dbg) diag_node_end(g.diag, nwg, round, st);
 #endif
@@ -1145,8 +1162,11 @@ hipError_t launch_node_final(const float* w, const GraphBufs& g, int round, floa
     GDev d = to_dev(w, g);
     set_round(d, g, round);
     d.clamp = clamp; d.pred_pos = pred_pos; d.pred_motion = pred_motion;
-    if (d.wb3) hipLaunchKernelGGL(k_node_prop_b3<true>, dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
-    else hipLaunchKernelGGL(k_node_prop<true>, dim3(node_grid(g)), dim3(WG), 0, st, d);
+    if (d.wb3) {
+        if (d.C_share) hipLaunchKernelGGL((k_node_prop_b3<true, true>), dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
+        else hipLaunchKernelGGL((k_node_prop_b3<true, false>), dim3(node_grid_b3(g)), dim3(WGB), 0, st, d);
+    } else if (d.C_share) hipLaunchKernelGGL((k_node_prop<true, true>), dim3(node_grid(g)), dim3(WG), 0, st, d);
+    else hipLaunchKernelGGL((k_node_prop<true, false>), dim3(node_grid(g)), dim3(WG), 0, st, d);
     return hipGetLastError();
 }
 

@@ -19,7 +19,9 @@
  *     comment says so.
  *   - The caller owns every input/output buffer.  The library owns only its
  *     ctx workspace (grown monotonically, freed by ag_ctx_destroy).
- *   - One ctx per (process, device); a ctx is not re-entrant.
+ *   - One ctx per (process, device); a ctx is not re-entrant.  All rollout calls of a ctx (ag_rollout, ag_rollout_async,
+ *     ag_rollout_actions) must be issued on ONE stream, or serialised by the caller: the launch plan, the repeat table and
+ *     the workspace are per-ctx state that the kernels of a call read until that call's work has drained.
  *   - No float atomics anywhere: results are bit-reproducible and independent
  *     of how candidates are chunked or sharded across GPUs.
  */
@@ -40,7 +42,7 @@ extern "C" {
 #define AG_ERR_UNSUPPORTED -4  /* configuration outside what the kernels implement                            */
 #define AG_ERR_NO_WEIGHTS -5   /* forward/rollout before ag_ctx_load_weights                                   */
 
-#define AG_ABI_VERSION 5
+#define AG_ABI_VERSION 6
 #define AG_NUM_WEIGHT_TENSORS 22
 
 typedef struct ag_ctx ag_ctx;
@@ -103,9 +105,11 @@ int ag_ctx_set_precision(ag_ctx* ctx, int32_t mode);
 /* Tuning: candidates per launch wave of the rollout (0 = automatic). */
 int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
 
-/* Per-context switches between bit-identical execution paths (A/B measurements, tests).  A context takes its defaults
- * from the environment ONCE, at ag_ctx_create (AG_* name in brackets); afterwards only these calls change them, so two
- * contexts of one process can differ.  No call of the library reads the environment after ag_ctx_create.
+/* Per-context switches between bit-identical execution paths (A/B measurements, tests) - with ONE exception, "device_decode",
+ * which moves the cos / sin of the action decode to the device (see there).  A context takes its defaults
+ * from the environment ONCE, at ag_ctx_create (AG_* name in brackets; values outside an option's range are clamped into it);
+ * afterwards only these calls change them, so two contexts of one process can differ.  No call of the library reads the
+ * environment after ag_ctx_create.
  *   "streams"        [AG_STREAMS]         in-library HIP streams of a rollout: 0 = by batch size (default), 1..4
  *   "chunk"          [AG_CHUNK]           candidates per launch chunk, 0 = automatic (ag_ctx_set_chunk takes precedence)
  *   "latency"        [AG_LATENCY]         latency-mode chains: -1 by launch size (default), 0 never, 1 always
@@ -120,8 +124,18 @@ int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
  *   "zigzag"         [AG_ZIGZAG]          odd message-passing rounds walk the row tiles backwards (default 1; Infinity-Cache reuse of
  *                                         the C rows the previous round read last)
  *   "device_decode"  [AG_DEVICE_DECODE]   consumed by the Python shim: dynamics() with GPU-resident actions goes through
- *                                         ag_rollout_actions: -1 when task_config bounds the repeat (default), 0 never, 1 always
- * Unknown names return AG_ERR_INVALID. */
+ *                                         ag_rollout_actions: -1 when task_config bounds the repeat (default), 0 never, 1 always.
+ *                                         NOT bit-neutral: the decode's cos / sin are then the device's, 'action_seqs' agrees
+ *                                         with a host decode to ~1e-7 (and a rollout can part from the host-decoded one at a
+ *                                         near-tie of the edge selection).  No reference fixture pins GPU-evaluated trig:
+ *                                         parity unpinned for that decode; the goldens are compared on the host-decode path
+ *   "share_first"    [AG_SHARE_FIRST]     first forward of an ag_rollout* call with y_mode 0 (one start state broadcast to all
+ *                                         candidates, forward_dynamics.py:25): the relation encoder runs once over the
+ *                                         object-object edges of the start state's tool-free graph, every candidate reads those
+ *                                         C rows; -1 = batches of >= 8 candidates (default), 0 never, 1 whenever possible
+ * Unknown names and values outside an option's range return AG_ERR_INVALID (ranges: streams 0..4, chunk 0..2^20, latency -1..1,
+ * the 0/1 switches 0..1, edge_wgs 1..65536, edge_block_min -1..INT32_MAX, enc_persist 0..2^20, stagger_us 0..1000,
+ * device_decode -1..1, share_first -1..1). */
 int ag_ctx_set_option(ag_ctx* ctx, const char* name, int32_t value);
 int ag_ctx_get_option(ag_ctx* ctx, const char* name, int32_t* out_value);
 
@@ -131,6 +145,13 @@ int ag_ctx_get_option(ag_ctx* ctx, const char* name, int32_t* out_value);
  * a launch chunk is stepped to the chunk's maximum, as the reference steps the whole batch to the batch maximum
  * (forward_dynamics.py:156-161).  After ag_rollout_actions the call waits for the device (the sums live there). */
 int ag_ctx_rollout_counts(ag_ctx* ctx, int64_t* out_executed, int64_t* out_needed);
+
+/* Shared first forward ("share_first") of the LAST ag_rollout / ag_rollout_async / ag_rollout_actions call on this context:
+ * out3[0] = edges the once-per-call base encode ran over (0 when the call did not share), out3[1] = edge slots of all
+ * candidates that took their C row from the shared table, out3[2] = edge slots the candidates encoded themselves at that
+ * forward (edges with a tool at either end).  Without sharing the relation encoder would have run over out3[1] + out3[2]
+ * edges.  Waits for the device. */
+int ag_ctx_share_counts(ag_ctx* ctx, int64_t* out3);
 
 /* Replaces construct_edges_from_states_batch (src/dynamics/dataset/graph.py:233-298).
  *   d_pos (B,N,3); d_mask,d_tool_mask (B,N) uint8; adj_thresh scalar, or d_adj_thresh_vec (B,) if non-NULL.

@@ -64,24 +64,89 @@ def timed(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def homogeneous(mat, Bn, H, R, reps):
+FAMILIES = ["edge_count", "edge_emit", "node_enc", "edge_enc", "node_prop", "node_final", "roll_init", "roll_update"]
+
+
+def start_graph_edges(task, clouds, masks, eef_xz):
+    """(edges, encoded = non-self-loop edges) of the START graphs of a batch: clouds (B,N_o,3), masks (B,N_o) bool,
+    eef_xz (B,M,2) tool keypoints; the tool sits at the cloud's lowest valid y (forward_dynamics.py:40).  The counts move by a
+    few edges over a rollout; they price the edge chain's algorithmic FLOPs (140,100 per encoded edge)."""
+    Bn, N_o, M = clouds.shape[0], clouds.shape[1], eef_xz.shape[1]
+    y = np.where(masks, clouds[..., 1], np.inf).min(1)
+    tool = np.stack([eef_xz[..., 0], np.repeat(y[:, None], M, 1), eef_xz[..., 1]], -1).astype(np.float32)
+    pos = torch.from_numpy(np.concatenate([clouds, tool], 1)).to(dev)
+    mask = torch.from_numpy(np.concatenate([masks, np.ones((Bn, M), bool)], 1)).to(dev)
+    tmask = torch.zeros((Bn, N_o + M), dtype=torch.bool, device=dev)
+    tmask[:, N_o:] = True
+    E = Enc = 0
+    for b0 in range(0, Bn, 64):
+        el = ag.construct_edges_index(pos[b0:b0 + 64], task["adj_thresh"], mask[b0:b0 + 64], tmask[b0:b0 + 64], task["topk"],
+                                      task["connect_tools_all"])
+        n = el.n_edges.long()
+        live = torch.arange(el.edge_cap, device=dev)[None, :] < n[:, None]
+        E += int(n.sum())
+        Enc += int(n.sum()) - int(((el.recv == el.send) & live).sum())
+    return E, Enc
+
+
+def kernel_report(engines, fn, n_enc_edge_forwards, n_node_forwards, wall_ms):
+    """One more call with HIP events around every launch (engine pinned to one stream): ms per family, the dominant kernel's
+    algorithmic rate against the fp32 MFMA peak, and the edge builder's share of the single-stream kernel time."""
+    for e in engines:
+        e.reset_stats(); e.set_profiling(FAMILIES)
+    fn(); torch.cuda.synchronize()
+    fam = {f: [0.0, 0] for f in FAMILIES}
+    for e in engines:
+        for f in FAMILIES:
+            ms, n = e.kernel_stats(f)
+            fam[f][0] += ms; fam[f][1] += n
+        e.set_profiling([]); e.reset_stats()
+    total = sum(v[0] for v in fam.values())
+    dom = max(fam, key=lambda f: fam[f][0])
+    flop = {"edge_enc": B.FLOP_PER_EDGE * n_enc_edge_forwards, "node_prop": B.FLOP_PER_NODE_PROP * n_node_forwards * 2,
+            "node_final": B.FLOP_PER_NODE_FINAL * n_node_forwards}
+    rep = {"kernel_ms_single_stream": {f: round(v[0], 3) for f, v in fam.items() if v[1]},
+           "launches": {f: v[1] for f, v in fam.items() if v[1]}, "kernel_ms_total": total,
+           "dominant_kernel": dom, "dominant_share": fam[dom][0] / total,
+           "edge_builder_share": (fam["edge_count"][0] + fam["edge_emit"][0]) / total}
+    for f, fl in flop.items():
+        if fam[f][0] > 0:
+            tf = fl / (fam[f][0] * 1e-3) / 1e12
+            rep[f] = {"algorithmic_flop": fl, "ms": fam[f][0], "tflops": tf, "frac_of_fp32_mfma_peak": tf / B.PEAK_FP32_MFMA_TFLOPS}
+    f_exec = sum(flop.values())
+    rep["end_to_end_frac_of_fp32_mfma_peak"] = f_exec / (wall_ms * 1e-3) / 1e12 / B.PEAK_FP32_MFMA_TFLOPS
+    return rep
+
+
+def homogeneous(mat, Bn, H, R, reps, report=True):
     rng = np.random.default_rng(0)
     cloud = cloud_of(mat, rng)
     task = task_of(mat, cloud.shape[0])
     task["action_upper_lim"] = [0.0, 4.5, 3.14, float(R)]          # bounds the repeat: GPU-resident actions take ag_rollout_actions
     m, s0 = model_of(mat), torch.from_numpy(cloud).to(dev)
-    a = torch.from_numpy(B.make_actions(Bn, H, R, cloud, rng)).to(dev)
+    a_np = B.make_actions(Bn, H, R, cloud, rng)
+    a = torch.from_numpy(a_np).to(dev)
     ppm = ppm_of(task, mat)
-    dt = timed(lambda: ag.dynamics(s0, a, m, dev, ppm), reps)
-    return {"config": f"{mat} {cloud.shape[0]}+{task['eef_num']} particles, {Bn} candidates x {H * R} steps",
-            "ms_per_call": dt * 1e3, "rollout_steps_per_s": Bn * H * R / dt}
+    fn = lambda: ag.dynamics(s0, a, m, dev, ppm)
+    dt = timed(fn, reps)
+    out = {"config": f"{mat} {cloud.shape[0]}+{task['eef_num']} particles, {Bn} candidates x {H * R} steps",
+           "ms_per_call": dt * 1e3, "rollout_steps_per_s": Bn * H * R / dt}
+    if report:
+        N_o, M = cloud.shape[0], task["eef_num"]
+        dec, _ = ag.decode_action(torch.from_numpy(a_np[:, :1]), push_length=task["push_length"])
+        from adaptigraph_amd.forward_dynamics import _tool_layout
+        xz, _ = _tool_layout(dec, torch.from_numpy(a_np[:, :1, 2]), task)
+        E, Enc = start_graph_edges(task, np.repeat(cloud[None], Bn, 0), np.ones((Bn, N_o), bool), xz[:, 0].numpy())
+        out.update(edges_per_graph=E / Bn, edges_encoded_per_graph=Enc / Bn)
+        out.update(kernel_report([m.engine(dev)], fn, Enc * H * R, Bn * (N_o + M) * H * R, dt * 1e3))
+    return out
 
 
-def mixed(total, steps, reps):
+def mixed(total, steps, reps, report=True):
     """cfg 5: a third of the batch per material, every candidate with its own particle count U{N/2..N} (padded + masked);
     dynamics_masked advances one look-ahead step of `steps` repeats."""
     rng = np.random.default_rng(1)
-    calls, n_steps = [], 0
+    calls, n_steps, engines, enc_fwd, node_fwd = [], 0, [], 0, 0
     for mat, nb in (("rope", total // 3 + total % 3), ("granular", total // 3), ("cloth", total // 3)):
         cloud = cloud_of(mat, rng)
         N = cloud.shape[0]
@@ -95,12 +160,30 @@ def mixed(total, steps, reps):
         args = (torch.from_numpy(state).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(a).to(dev))
         calls.append(lambda args=args, m=m, ppm=ppm: ag.dynamics_masked(*args, m, dev, ppm))
         n_steps += nb * steps
-    dt = timed(lambda: [c() for c in calls], reps)
-    return {"config": f"mixed rope+granular+cloth, {total} variable-size graphs x {steps} steps", "ms_per_call": dt * 1e3,
-            "rollout_steps_per_s": n_steps / dt}
+        engines.append(m.engine(dev))
+        if report:
+            from adaptigraph_amd.forward_dynamics import _tool_layout
+            dec, _ = ag.decode_action(torch.from_numpy(a[:, None]), push_length=task["push_length"])
+            xz, _ = _tool_layout(dec, torch.from_numpy(a[:, None, 2]), task)
+            _, Enc = start_graph_edges(task, state, mask, xz[:, 0].numpy())
+            enc_fwd += Enc * steps
+            node_fwd += (int(mask.sum()) + nb * task["eef_num"]) * steps
+    fn = lambda: [c() for c in calls]
+    dt = timed(fn, reps)
+    out = {"config": f"mixed rope+granular+cloth, {total} variable-size graphs x {steps} steps", "ms_per_call": dt * 1e3,
+           "rollout_steps_per_s": n_steps / dt}
+    if report:
+        out.update(kernel_report(engines, fn, enc_fwd, node_fwd, dt * 1e3))
+    return out
 
+
+CONFIGS = {"rope1": lambda: homogeneous("rope", 1, 1, 10, 20), "rope64": lambda: homogeneous("rope", 64, 2, 10, 10),
+           "granular": lambda: homogeneous("granular", 256, 2, 10, 3), "mixed": lambda: mixed(512, 20, 3)}
 
 if __name__ == "__main__":
-    for r in (homogeneous("rope", 1, 1, 10, 20), homogeneous("rope", 64, 2, 10, 10), homogeneous("granular", 256, 2, 10, 3),
-              mixed(512, 20, 3)):
-        print(json.dumps(r))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="comma-separated subset of " + ",".join(CONFIGS))
+    args = ap.parse_args()
+    for name in (args.only.split(",") if args.only else CONFIGS):
+        print(json.dumps(dict(name=name, **CONFIGS[name]())), flush=True)
