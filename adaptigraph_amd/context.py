@@ -125,6 +125,12 @@ class Engine:
         self.check(self.lib.ag_ctx_rollout_counts(self._ctx, C.byref(ex), C.byref(need)))
         return ex.value, need.value
 
+    def launch_counts(self):
+        """(model forwards per launch chunk enqueued by the last rollout call, what the loop bounds alone give): ag_ctx_launch_counts."""
+        out = (C.c_int64 * 2)()
+        self.check(self.lib.ag_ctx_launch_counts(self._ctx, out))
+        return int(out[0]), int(out[1])
+
     def share_counts(self):
         """Shared first forward of the last rollout call (ag_ctx_share_counts): (edges of the once-per-call base encode,
         edge slots served by the shared table, edge slots the candidates encoded themselves at that forward)."""

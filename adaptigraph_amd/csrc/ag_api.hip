@@ -66,6 +66,9 @@ struct ag_ctx {
     long long fwd_executed = 0, fwd_needed = 0;       // candidate-forwards of the last rollout call (ag_ctx_rollout_counts)
     char* d_plan = nullptr; size_t plan_cap = 0;      // device-planned rollouts (ag_rollout_actions): decoded tool keypoints,
     int* d_plan_sums = nullptr; int plan_sums_n = 0;  // repeats, launch order and per-step live counts; sums pending a read-back
+    int* h_plan_max = nullptr; size_t plan_max_cap = 0;   // pinned host copy of RollPlan::maxrep of the call being enqueued
+    hipEvent_t ev_plan = nullptr;                       // fires when that copy has landed
+    long long steps_enqueued = 0, steps_bound = 0;      // model forwards (per chunk) enqueued by the last rollout call / what the bound alone gives
     int* d_overflow = nullptr;
     unsigned long long* d_share_stats = nullptr;      // shared first forward: [0] slots served by the base table, [1] slots encoded per candidate
     const int* d_share_nns = nullptr;                 // edges the base encode ran over (workspace of the last rollout call), or null
@@ -511,6 +514,8 @@ int ag_ctx_destroy(ag_ctx* c) {
     for (auto& p : c->prof_live) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
+    if (c->h_plan_max) (void)hipHostFree(c->h_plan_max);
     for (int i = 1; i < ag_ctx::kMaxStreams; ++i) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->aux_stream[i]) (void)hipStreamDestroy(c->aux_stream[i]);
@@ -574,6 +579,12 @@ int ag_ctx_rollout_counts(ag_ctx* c, int64_t* out_executed, int64_t* out_needed)
         c->d_plan_sums = nullptr;
     }
     *out_executed = c->fwd_executed; *out_needed = c->fwd_needed;
+    return AG_OK;
+}
+
+int ag_ctx_launch_counts(ag_ctx* c, int64_t* out2) {
+    if (!c || !out2) return AG_ERR_INVALID;
+    out2[0] = c->steps_enqueued; out2[1] = c->steps_bound;
     return AG_OK;
 }
 
@@ -914,7 +925,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         // chunk's candidates by action_repeat and tabulates how many are live at every step; the launches below take their
         // live counts from that table (device memory), so nothing of the actions ever crosses to the host.
         const size_t tab = (size_t)n_chunks_all * p->H * (R + 2);
-        const size_t n_int = 2 * nrep + 2 * tab + (size_t)n_chunks_all * p->H * 2;
+        const size_t n_int = 2 * nrep + 2 * tab + (size_t)n_chunks_all * p->H * 3;
         const size_t n_flt = nrep * p->M * 5;
         const size_t bytes = round_up(n_int * 4, 256) + n_flt * 4;
         if (c->plan_cap < bytes) {
@@ -932,7 +943,22 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         rp.B = p->B; rp.H = p->H; rp.Bc = Bc; rp.N = N; rp.max_repeat = R;
         rp.decoded = src.d_action_seqs; rp.eef_xz = pl_xz; rp.eef_delta = pl_delta; rp.repeat = pl_repeat; rp.cand = pl_cand;
         rp.live = pl_live; rp.rows = pl_rows; rp.sums = pl_sums; rp.flags = d_overflow_flag; rp.sort = sort_on ? 1 : 0;
+        rp.maxrep = pl_sums + (size_t)n_chunks_all * p->H * 2;
         HIPCHK(c, launch_roll_plan(rp, st));
+        // Every (chunk, look-ahead step)'s own maximum comes back into pinned host memory behind an event - asynchronously:
+        // nothing waits for it.  The enqueue loop below polls the event (hipEventQuery) and, once it has fired, stops enqueuing
+        // a look-ahead step's repeats at that maximum instead of at the caller's bound (whose surplus steps would find no live
+        // slot: full grids of workgroups that exit).  Until it fires the loop goes by the bound, as before.
+        const size_t n_max = (size_t)n_chunks_all * p->H;
+        if (c->plan_max_cap < n_max) {
+            if (c->h_plan_max) HIPCHK(c, hipHostFree(c->h_plan_max));
+            c->h_plan_max = nullptr; c->plan_max_cap = 0;
+            HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_plan_max), (n_max + 64) * 4, hipHostMallocDefault));
+            c->plan_max_cap = n_max + 64;
+        }
+        if (!c->ev_plan) HIPCHK(c, hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
+        HIPCHK(c, hipMemcpyAsync(c->h_plan_max, rp.maxrep, n_max * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipEventRecord(c->ev_plan, st));
         d_eef_xz = pl_xz; d_eef_delta = pl_delta;
         c->d_plan_sums = pl_sums; c->plan_sums_n = n_chunks_all * p->H;
         c->fwd_executed = -1; c->fwd_needed = -1;
@@ -1020,6 +1046,8 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     // below, so that a failure in the middle never leaves work of this call in flight on a stream the caller cannot see.
     auto enqueue_chunks = [&]() -> int {
     bool obj_cls_ready[ag_ctx::kMaxStreams] = {false, false, false, false};   // per workspace, per call
+    bool plan_landed = false;                                // device plan: the chunk maxima are in c->h_plan_max
+    c->steps_enqueued = 0; c->steps_bound = 0;
     int ci = 0;
     for (int b0 = 0; b0 < p->B; b0 += Bc, ++ci) {
         if (ci == fail_at) return fail(c, AG_ERR_HIP, "test hook: injected failure before chunk %d", ci);
@@ -1077,7 +1105,17 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
               else HIPCHK(c, launch_node_enc(c->d_w, g, tool0, (long)nb * p->M, cs)); }
             obj_cls_ready[ci % ns] = true;
             int n_live = nb;
+            c->steps_bound += max_rep;
             for (int ai = 1; ai <= max_rep; ++ai) {           // forward_dynamics.py:156
+                if (dev_plan) {
+                    // past this chunk's own maximum no slot is live: stop as soon as the plan's maxima are known (no waiting)
+                    if (!plan_landed && ai > 1) {
+                        if (hipEventQuery(c->ev_plan) == hipSuccess) plan_landed = true;
+                        else (void)hipGetLastError();       // "not ready" must not be taken for a failed launch by the next check
+                    }
+                    if (plan_landed && ai > c->h_plan_max[(size_t)ci * p->H + li]) break;
+                }
+                ++c->steps_enqueued;
                 if (dev_plan) {   // grids cover the whole chunk; the kernels read how many slots are live from the plan's table
                     ea.live = live_row + ai; ra.live = live_row + ai; g.n_rows = rows_row + ai;
                 } else {

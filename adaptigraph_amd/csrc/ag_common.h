@@ -266,6 +266,7 @@ struct RollPlan {
     int* cand;                  // (H,B) slot -> candidate, per chunk segment
     int* live; int* rows;       // (n_chunks, H, max_repeat + 2): candidates live at step ai, and that times N
     int* sums;                  // (n_chunks, H, 2): sum of min(repeat, max_repeat), sum of live over the steps
+    int* maxrep;                // (n_chunks, H): largest min(repeat, max_repeat) of the chunk = steps that find a live slot
     int* flags;                 // caller's flag words: [1] = atomicMax of a repeat beyond max_repeat
     int sort;                   // 0: keep the candidate order (live counts then stay at the chunk size while any candidate is live)
 };

@@ -368,6 +368,9 @@ __global__ __launch_bounds__(64) void k_roll_plan(RollPlan p) {
         }
         p.sums[((long)ci * p.H + li) * 2 + 0] = sum_rep;
         p.sums[((long)ci * p.H + li) * 2 + 1] = sum_live;
+        int mx = 0;
+        for (int v = 1; v <= R; ++v) if (hist[v] > 0) mx = v;
+        p.maxrep[(long)ci * p.H + li] = mx;
     }
     __syncthreads();
     for (int v = lane; v <= R; v += 64) hist[v] = 0;         // reused as the running fill of every bucket

@@ -106,8 +106,10 @@ def _repeat_bound(task):
         return None
 
 
-def _run_device_actions(model, eng, dev, task, ppm_optimizer, physics_param, action, state0, bound, sync, flags):
-    """ag_rollout_actions: decode + launch plan on the device (see module docstring)."""
+def _run_device_actions(model, eng, dev, task, ppm_optimizer, physics_param, action, state0, bound, sync, flags, strict):
+    """ag_rollout_actions: decode + launch plan on the device (see module docstring).  Returns (state_seqs, decoded), or None
+    when a repeat count beyond `bound` was seen and `strict` is off (the caller then takes the host-decode path, which - like
+    the reference, forward_dynamics.py:156 - accepts any action length)."""
     assert int(task["n_his"]) == model.n_his, "task_config['n_his'] (forward_dynamics.py:16) must be the model's n_his"
     B, H = action.shape[0], action.shape[1]
     N_o, M = state0.shape[0], ppm_optimizer.eef_num
@@ -135,9 +137,17 @@ def _run_device_actions(model, eng, dev, task, ppm_optimizer, physics_param, act
         if seen[0] > int(task["max_nR"]):
             raise Exception("Exceeds max dims")                                        # utils.py:63-65
         if seen[1] > bound:
+            if not strict:
+                return None
             raise ValueError(f"an action's repeat count {seen[1]} exceeds the task config's action_upper_lim[3] = {bound}: "
                              "the device-planned rollout launches every look-ahead step that many times (pass actions "
-                             "within the limits, or set option device_decode = 0)")
+                             "within the limits, or leave option device_decode at -1 / 0)")
+    else:
+        # no wait, so no second chance: a candidate whose repeat exceeds the bound was stepped only `bound` times and never
+        # captured.  Its rows must not look like a valid (all-zero) state to a cost function that does not read flags[1]:
+        # they become NaN (two small device ops, no sync; flags[1] still reports the count)
+        over = (act[..., 3].to(torch.int32) > int(bound)).any(dim=1)
+        out.masked_fill_(over[:, None, None, None], float("nan"))
     return out, decoded
 
 
@@ -153,11 +163,16 @@ def dynamics(state, action, model, device, ppm_optimizer, physics_param=None, _s
         bound = _repeat_bound(task)
         if mode == 1 and bound is None:
             raise ValueError("option device_decode = 1 needs task_config['action_upper_lim'] (the bound of action_repeat)")
-        if mode != 0 and bound is not None:
+        # automatic mode (-1) never narrows the reference's contract: a bound the device plan cannot serve (outside
+        # [0, 1024], more than 8 tool points) or - when this call waits for its result anyway - a repeat beyond the bound
+        # sends the call down the host-decode path, which steps to any repeat count (forward_dynamics.py:156)
+        servable = bound is not None and 0 <= bound <= 1024 and ppm_optimizer.eef_num <= 8
+        if mode == 1 or (mode != 0 and servable):
             state0 = state.detach().to(dev, torch.float32).contiguous()
-            out, decoded = _run_device_actions(model, eng, dev, task, ppm_optimizer, physics_param, action, state0, bound,
-                                               _sync, _overflow_flag)
-            return {"state_seqs": out, "action_seqs": decoded.to(action.device)}
+            res = _run_device_actions(model, eng, dev, task, ppm_optimizer, physics_param, action, state0, bound,
+                                      _sync, _overflow_flag, strict=(mode == 1))
+            if res is not None:
+                return {"state_seqs": res[0], "action_seqs": res[1].to(action.device)}
     action_cpu = action.detach().to("cpu", torch.float32)
     decoded, repeat = decode_action(action_cpu, push_length=task["push_length"])          # :23
     xz, delta = _tool_layout(decoded, action_cpu[:, :, 2], task)

@@ -10,6 +10,9 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+# True: a world of ONE rank still issues its all-gather (bench.py AG_BENCH_FORCE_DIST=1: executes the RCCL calls on a one-GPU box)
+FORCE_COLLECTIVES = False
+
 
 def shard_bounds(n_candidates: int, world: int, rank: int):
     """Contiguous, balanced shards; the first (n % world) ranks get one extra candidate."""
@@ -42,7 +45,7 @@ def shard_bounds_weighted(weights, world: int, rank: int):
 def all_gather_costs(cost_local: torch.Tensor, n_candidates: int, group=None, bounds=None) -> torch.Tensor:
     """cost_local: (hi-lo,) costs of this rank's shard -> (n_candidates,) costs of the whole batch on every rank.
     bounds: optional list of (lo, hi) per rank for work-balanced shards (default: shard_bounds)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES):
         assert cost_local.numel() == n_candidates
         return cost_local
     world = dist.get_world_size(group)

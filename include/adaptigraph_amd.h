@@ -146,6 +146,13 @@ int ag_ctx_get_option(ag_ctx* ctx, const char* name, int32_t* out_value);
  * (forward_dynamics.py:156-161).  After ag_rollout_actions the call waits for the device (the sums live there). */
 int ag_ctx_rollout_counts(ag_ctx* ctx, int64_t* out_executed, int64_t* out_needed);
 
+/* Model forwards (per launch chunk and look-ahead step) ENQUEUED by the LAST ag_rollout / ag_rollout_async /
+ * ag_rollout_actions call: out2[0] = enqueued, out2[1] = what the loop bounds alone give (host plan: the chunk maxima, equal
+ * to out2[0]; device plan: max_repeat per chunk and look-ahead step).  On the device-planned path the chunk maxima come back
+ * to the host asynchronously (pinned memory + event, never waited for); once they have landed the enqueue loop stops a
+ * look-ahead step at the chunk's own maximum, so out2[0] <= out2[1].  Host bookkeeping only: no device access. */
+int ag_ctx_launch_counts(ag_ctx* ctx, int64_t* out2);
+
 /* Shared first forward ("share_first") of the LAST ag_rollout / ag_rollout_async / ag_rollout_actions call on this context:
  * out3[0] = edges the once-per-call base encode ran over (0 when the call did not share), out3[1] = edge slots of all
  * candidates that took their C row from the shared table, out3[2] = edge slots the candidates encoded themselves at that
@@ -237,8 +244,9 @@ int ag_rollout_async(ag_ctx* ctx, void* stream, const ag_rollout_params* p, cons
  *   d_action        (B,H,4) raw [x, z, theta, length]
  *   push_length     task_config push_length;  h_tool_offsets (M,) HOST: pusher_points[k][1] * sim_real_ratio (entry 0 unused;
  *                   may be NULL when M == 1)
- *   max_repeat      upper bound of action_repeat = int(length) the caller guarantees (e.g. its action_upper_lim[3]); every
- *                   look-ahead step is launched max_repeat times, steps past a chunk's own maximum find no live slot and exit
+ *   max_repeat      upper bound of action_repeat = int(length) the caller guarantees (e.g. its action_upper_lim[3]); a
+ *                   look-ahead step is launched at most max_repeat times: steps past a chunk's own maximum find no live slot
+ *                   and exit, and are no longer enqueued once the plan's maxima have reached the host (ag_ctx_launch_counts)
  *   d_action_seqs   (B,H,4) output: decoded actions [x_start, z_start, x_end, z_end] (the reference's 'action_seqs')
  *   d_flags         (>= 2 int32, device, caller-zeroed): [0] max edge count seen if it exceeded max_nR (as ag_rollout_async),
  *                   [1] largest action_repeat seen if it exceeded max_repeat (the results of such a candidate are invalid)

@@ -2,7 +2,7 @@
 
 Run as a CHILD process by bench.py's cpu_baseline leg (the bench process has initialised the GPU and must not fork):
 
-    python -m oracle.cpu_baseline <in.npz> <out.npz> <workers>
+    python -m oracle.cpu_baseline <in.npz> <out.npz> <workers> [<blas threads per worker, default 1>]
 
 in.npz : cloud (N_o,3), actions (P,H,4) = P candidates of the timed batch, task_json, pstep, w::<state_dict key> ...
 out.npz: state_seqs (P,H,N_o,3) of those candidates (bench.py compares them with the GPU results: parity_check),
@@ -47,8 +47,9 @@ def _margins(job):
 
 def main(argv):
     src, dst, workers = argv[1], argv[2], int(argv[3])
+    blas = str(max(1, int(argv[4]))) if len(argv) > 4 else "1"
     for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ[v] = "1"                                  # before numpy loads its BLAS, inherited by the workers
+        os.environ[v] = blas                                 # before numpy loads its BLAS, inherited by the workers
     import numpy as np
     import multiprocessing as mp
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

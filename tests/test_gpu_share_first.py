@@ -131,3 +131,34 @@ def test_option_values_outside_their_range_are_refused(ag, O, dev):
         with pytest.raises(AssertionError, match="outside"):
             eng.set_option(name, bad)
         assert eng.get_option(name) == before
+
+
+def test_device_planned_rollout_stops_enqueuing_at_the_chunk_maximum(ag, O, dev):
+    """ag_rollout_actions enqueues a look-ahead step at most action_upper_lim[3] times; the chunk maxima come back to the host
+    asynchronously (pinned memory + event, polled, never waited for) and the loop then stops at them: a 500-candidate call whose
+    lengths are all <= 6 under a bound of 15 enqueues about 6 steps per chunk instead of 15.  Same bits as the host-planned path
+    on the same decoded actions is not required here (device cos/sin); the results must equal the full-bound run bit for bit."""
+    rng = np.random.default_rng(307)
+    task = _task("rope", max_nR=40000, action_lower_lim=[-4.5, -2.5, -3.14, 2.0], action_upper_lim=[0.0, 4.5, 3.14, 15.0])
+    W, m = _model(ag, O, "rope", 307, dev)
+    cloud = _rope(200, rng)
+    B = 500
+    reps = rng.integers(2, 7, (B, 1))
+    a = torch.from_numpy(_actions(cloud, B, 1, reps, rng, spread=0.8)).to(dev)
+    s0 = torch.from_numpy(cloud).to(dev)
+    ppm = _ppm(task, "rope")
+    eng = m.engine(dev)
+    for streams in (1, 4):
+        with eng.options(streams=streams):
+            torch.cuda.synchronize()
+            got = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]
+            enq, bound = eng.launch_counts()
+            ex, need = eng.rollout_counts()
+        n_chunks = bound // 15
+        assert bound == 15 * n_chunks and need == int(reps.sum()) and ex == need
+        # per chunk: its own maximum (6), plus whatever was enqueued before the plan's maxima landed (first chunk only)
+        assert 6 * n_chunks <= enq <= 6 * n_chunks + 9, (enq, bound, n_chunks)
+        print(f"streams {streams}: {enq} steps enqueued for {n_chunks} chunk(s) (bound alone: {bound})")
+        tight = dict(task, action_upper_lim=[0.0, 4.5, 3.14, 6.0])
+        ref = ag.dynamics(s0, a, m, dev, _ppm(tight, "rope"))["state_seqs"]
+        assert torch.equal(got, ref)

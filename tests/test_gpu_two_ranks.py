@@ -2,8 +2,9 @@
 them, both mapped onto the one GPU of the box (AG_BENCH_SHARE_GPU=1) with gloo in RCCL's place (RCCL refuses two ranks on
 one device) - shards, per-rank rollouts, the MAX all-reduce of the two batch-global scalars and the all-gather of the
 rewards all run.  The gathered reward vector must equal the one-rank run's bit for bit (candidates are independent; no
-float atomics).  Children only: this process never re-executes itself.  RCCL itself has still never seen more than one
-rank (no multi-GPU node has been available): DESIGN.md section 6."""
+float atomics).  Children only: this process never re-executes itself.  RCCL itself executes the same collectives with a
+world of ONE rank (test below); it has still never seen more than one rank (no multi-GPU node has been available):
+DESIGN.md section 6."""
 import json
 import os
 import socket
@@ -30,18 +31,52 @@ def _line(out):
     return json.loads(rows[0])
 
 
+_ONE = {}
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "AG_BENCH_FORCE_DIST", "AG_BENCH_BACKEND", "AG_BENCH_SHARE_GPU")}
+
+
+def _one_rank_line():
+    """the plain one-rank bench line (no process group), run once per test session in a child process"""
+    if "line" not in _ONE:
+        one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + ARGS, env=_clean_env(), cwd=ROOT,
+                             capture_output=True, text=True, timeout=900)
+        assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+        _ONE["line"] = _line(one.stdout)
+    return _ONE["line"]
+
+
+def test_one_rank_runs_the_rccl_collectives_and_equals_the_plain_run():
+    """AG_BENCH_FORCE_DIST=1: `bench.py --gpus 1` initialises the nccl (= RCCL) backend with a world of one (communicator
+    created on device_id) and goes through sharded_candidate_rewards -> all_gather_costs -> dist.all_gather_into_tensor and both
+    MAX all-reduces of running_cost / cloth_penalty ON RCCL - the calls a multi-GPU run makes, on the hardware that exists.
+    Fresh child process (never a re-exec of one that touched the GPU).  Same reward bits as the plain run."""
+    l1 = _one_rank_line()
+    env = dict(_clean_env(), AG_BENCH_FORCE_DIST="1")
+    forced = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + ARGS, env=env, cwd=ROOT,
+                            capture_output=True, text=True, timeout=900)
+    assert forced.returncode == 0, forced.stdout[-2000:] + forced.stderr[-4000:]
+    lf = _line(forced.stdout)
+    assert "multi_gpu" not in l1
+    mg = lf["multi_gpu"]
+    assert mg["backend"] == "nccl" and mg["candidates_per_rank"] == [64] and mg["exchange_us_per_step"] > 0, mg
+    assert lf["n_gpus"] == 1 and lf["reward_sha256"] == l1["reward_sha256"], (lf["reward_sha256"], l1["reward_sha256"])
+    print(f"one-rank RCCL exchange (all-reduce MAX of two scalars + all-gather of 64 rewards): {mg['exchange_us_per_step']:.1f} us per step")
+
+
 def test_two_ranks_on_one_gpu_equal_one_rank_bitwise():
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + ARGS, env=env, cwd=ROOT,
-                         capture_output=True, text=True, timeout=900)
-    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    env = _clean_env()
+    l1 = _one_rank_line()
     env2 = dict(env, AG_BENCH_SHARE_GPU="1", AG_BENCH_BACKEND="gloo")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS, env=env2, cwd=ROOT,
                          capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
-    l1, l2 = _line(one.stdout), _line(two.stdout)
+    l2 = _line(two.stdout)
     assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2
     assert l2["config"]["candidates"] == 64 and "sharded over 2 GPU(s)" in l2["config"]["parallelism"]
     assert l1["reward_sha256"] == l2["reward_sha256"], (l1["reward_sha256"], l2["reward_sha256"])
