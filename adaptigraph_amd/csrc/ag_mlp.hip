@@ -327,8 +327,8 @@ struct PassRow {
 // sjp = the edge's sender; SHARE (first forward of a dynamics() call): sender in the low 12 bits, above them position + 1
 // in the receiver's row of the base graph when the C row is the shared table's (GraphBufs::send_pk)
 template <bool SHARE>
-__device__ __forceinline__ void gather_issue(const GDev& g, const PassRow& r, bool cls, int k, int sjp, EdgeBuf& buf,
-                                             const float* __restrict__ C, const float* __restrict__ V, int lane) {
+__device__ __forceinline__ void gather_addr(const GDev& g, const PassRow& r, bool cls, int k, int sjp, const float* __restrict__ C,
+                                            const float* __restrict__ V, int lane, const float*& cp, const float*& vp) {
     const unsigned c4 = 4u * (lane & 7);
     const bool on = k < r.deg;
     const int sj = SHARE ? (sjp & 0xfff) : sjp;
@@ -339,13 +339,19 @@ __device__ __forceinline__ void gather_issue(const GDev& g, const PassRow& r, bo
     const unsigned crow = (!on || (g.dedupe && sj == r.i)) ? selfrow : (unsigned)r.b * (unsigned)g.c_cap + (unsigned)(r.e0 + k);
     const unsigned tool0 = (unsigned)g.N_o + (unsigned)r.b * g.M;            // + particle index (>= N_o) = class row
     const unsigned vrow = cls ? (sj >= g.N_o ? tool0 + (unsigned)sj : (unsigned)sj) : (unsigned)r.b * (unsigned)g.N + (unsigned)sj;
-    const float* cp = C + crow * (unsigned)NFP + c4;
+    cp = C + crow * (unsigned)NFP + c4;
     if (SHARE) {   // same bits as the candidate's own row would hold: a row's chain does not depend on where it is computed
         const unsigned sp = (unsigned)sjp >> 12;
         const float* sh = g.C_share + ((unsigned)r.i * g.share_kb + (sp - 1u)) * (unsigned)NFP + c4;
         cp = (on && sp != 0u) ? sh : cp;
     }
-    const float* vp = V + vrow * (unsigned)NFP + c4;
+    vp = V + vrow * (unsigned)NFP + c4;
+}
+template <bool SHARE>
+__device__ __forceinline__ void gather_issue(const GDev& g, const PassRow& r, bool cls, int k, int sjp, EdgeBuf& buf,
+                                             const float* __restrict__ C, const float* __restrict__ V, int lane) {
+    const float *cp, *vp;
+    gather_addr<SHARE>(g, r, cls, k, sjp, C, V, lane, cp, vp);
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
         buf.c[t] = *reinterpret_cast<const f32x4*>(cp + 32 * t);
