@@ -89,7 +89,7 @@ def start_graph_edges(task, clouds, masks, eef_xz):
     return E, Enc
 
 
-def kernel_report(engines, fn, n_enc_edge_forwards, n_node_forwards, wall_ms):
+def kernel_report(engines, fn, n_enc_edge_forwards, n_node_forwards, wall_ms, n_edge_forwards=None):
     """One more call with HIP events around every launch (engine pinned to one stream): ms per family, the dominant kernel's
     algorithmic rate against the fp32 MFMA peak, and the edge builder's share of the single-stream kernel time."""
     for e in engines:
@@ -113,6 +113,15 @@ def kernel_report(engines, fn, n_enc_edge_forwards, n_node_forwards, wall_ms):
         if fam[f][0] > 0:
             tf = fl / (fam[f][0] * 1e-3) / 1e12
             rep[f] = {"algorithmic_flop": fl, "ms": fam[f][0], "tflops": tf, "frac_of_fp32_mfma_peak": tf / B.PEAK_FP32_MFMA_TFLOPS}
+    # the propagate chains are bounded by both resources: compulsory HBM bytes per round = one 640-B C row per encoded edge,
+    # a 4-B index per edge, and six 640-B rows per particle (U, V, eff in; eff, U, V out) - the final round three
+    if n_edge_forwards is not None:
+        per_round = n_enc_edge_forwards * 640 + n_edge_forwards * 4
+        for f, rounds, rows in (("node_prop", 2, 6), ("node_final", 1, 3)):
+            if f in rep:
+                by = rounds * (per_round + n_node_forwards * 640 * rows)
+                gbs = by / (fam[f][0] * 1e-3) / 1e9
+                rep[f].update(compulsory_hbm_bytes=by, hbm_gbs=gbs, frac_of_hbm_peak=gbs / B.PEAK_HBM_GBS)
     f_exec = sum(flop.values())
     rep["end_to_end_frac_of_fp32_mfma_peak"] = f_exec / (wall_ms * 1e-3) / 1e12 / B.PEAK_FP32_MFMA_TFLOPS
     return rep
@@ -138,7 +147,7 @@ def homogeneous(mat, Bn, H, R, reps, report=True):
         xz, _ = _tool_layout(dec, torch.from_numpy(a_np[:, :1, 2]), task)
         E, Enc = start_graph_edges(task, np.repeat(cloud[None], Bn, 0), np.ones((Bn, N_o), bool), xz[:, 0].numpy())
         out.update(edges_per_graph=E / Bn, edges_encoded_per_graph=Enc / Bn)
-        out.update(kernel_report([m.engine(dev)], fn, Enc * H * R, Bn * (N_o + M) * H * R, dt * 1e3))
+        out.update(kernel_report([m.engine(dev)], fn, Enc * H * R, Bn * (N_o + M) * H * R, dt * 1e3, E * H * R))
     return out
 
 
@@ -146,7 +155,7 @@ def mixed(total, steps, reps, report=True):
     """cfg 5: a third of the batch per material, every candidate with its own particle count U{N/2..N} (padded + masked);
     dynamics_masked advances one look-ahead step of `steps` repeats."""
     rng = np.random.default_rng(1)
-    calls, n_steps, engines, enc_fwd, node_fwd = [], 0, [], 0, 0
+    calls, n_steps, engines, enc_fwd, node_fwd, edge_fwd = [], 0, [], 0, 0, 0
     for mat, nb in (("rope", total // 3 + total % 3), ("granular", total // 3), ("cloth", total // 3)):
         cloud = cloud_of(mat, rng)
         N = cloud.shape[0]
@@ -165,15 +174,16 @@ def mixed(total, steps, reps, report=True):
             from adaptigraph_amd.forward_dynamics import _tool_layout
             dec, _ = ag.decode_action(torch.from_numpy(a[:, None]), push_length=task["push_length"])
             xz, _ = _tool_layout(dec, torch.from_numpy(a[:, None, 2]), task)
-            _, Enc = start_graph_edges(task, state, mask, xz[:, 0].numpy())
+            E, Enc = start_graph_edges(task, state, mask, xz[:, 0].numpy())
             enc_fwd += Enc * steps
+            edge_fwd += E * steps
             node_fwd += (int(mask.sum()) + nb * task["eef_num"]) * steps
     fn = lambda: [c() for c in calls]
     dt = timed(fn, reps)
     out = {"config": f"mixed rope+granular+cloth, {total} variable-size graphs x {steps} steps", "ms_per_call": dt * 1e3,
            "rollout_steps_per_s": n_steps / dt}
     if report:
-        out.update(kernel_report(engines, fn, enc_fwd, node_fwd, dt * 1e3))
+        out.update(kernel_report(engines, fn, enc_fwd, node_fwd, dt * 1e3, edge_fwd))
     return out
 
 

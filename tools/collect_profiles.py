@@ -1,0 +1,65 @@
+"""Copy the summaries of an evidence run (tools/profile_round.sh -> gpurun_out/final, gpurun_out/cfg) into profiles/<round>_*.
+Only reductions are copied (json / jsonl / the rocprofv3 --stats csv); traces and counter dumps stay in gpurun_out/.
+  python tools/collect_profiles.py r04"""
+import csv, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1]
+F, C, P = (os.path.join(ROOT, "gpurun_out", d) for d in ("final", "cfg", "")); P = os.path.join(ROOT, "profiles")
+
+
+def bench_line(path):
+    return json.loads([l for l in open(path) if l.startswith("{")][0])
+
+
+def stats(src, dst):
+    """rocprofv3 --stats kernel table, our kernels and the few torch ones that matter (rows below 0.005 % dropped)"""
+    rows = list(csv.DictReader(open(src)))
+    keep = [r for r in rows if float(r["Percentage"]) >= 0.005 or "ag::" in r["Name"]]
+    with open(dst, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_ALL)
+        w.writeheader()
+        for r in keep:
+            r["Name"] = r["Name"][:160]
+            w.writerow(r)
+
+
+line = bench_line(os.path.join(F, "bench_default.json"))
+json.dump(line, open(os.path.join(P, f"{rnd}_bench_default.json"), "w"), indent=1)
+stats(os.path.join(F, "prof_default", "d_kernel_stats.csv"), os.path.join(P, f"{rnd}_bench_default_kernel_stats.csv"))
+stats(os.path.join(F, "prof_single", "s_kernel_stats.csv"), os.path.join(P, f"{rnd}_bench_single_stream_kernel_stats.csv"))
+E_enc, cand = line["config"]["edges_encoded_per_graph"], 128
+src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) --kernel-trace -- python3 bench.py --candidates 256 --steps 1 --warmup 0 "
+       "--no-cpu-baseline --no-bf16x3 --no-kernel-profile --no-mpc-iter, AG_STREAMS=1 AG_SHARE_FIRST=0 (tools/profile_round.sh); "
+       "tools/pmc_traffic.py")
+for src_name, dst_name in (("traffic_k_edge_enc.json", "traffic_k_edge_enc.json"), ("traffic_k_node_propfalse.json", "traffic_k_node_prop.json"),
+                           ("traffic_k_node_proptrue.json", "traffic_k_node_final.json")):
+    d = json.load(open(os.path.join(F, src_name)))
+    d.update(candidates_per_launch=cand, edges_per_launch=E_enc * cand, source=src)
+    json.dump(d, open(os.path.join(P, f"{rnd}_{dst_name}"), "w"), indent=1)
+pmc = json.load(open(os.path.join(F, "pmc_summary.json")))
+for n, c in pmc.items():
+    if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+        c["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (c["GRBM_GUI_ACTIVE"] / 8)
+json.dump(pmc, open(os.path.join(P, f"{rnd}_pmc_counters.json"), "w"), indent=1)
+shutil.copy(os.path.join(F, "planner_configs.jsonl"), os.path.join(P, f"{rnd}_planner_configs.jsonl"))
+with open(os.path.join(P, f"{rnd}_planner_configs.jsonl"), "a") as f:
+    for l in open(os.path.join(F, "planner_configs_share0.jsonl")):
+        r = json.loads(l); r["share_first"] = 0
+        f.write(json.dumps(r) + "\n")
+one, plain = bench_line(os.path.join(F, "bench_one_rank_rccl.json")), bench_line(os.path.join(F, "bench_plain_short.json"))
+json.dump({"what": "bench.py --gpus 1 --steps 5 --warmup 2 with AG_BENCH_FORCE_DIST=1: nccl (= RCCL) process group with a world of one rank, "
+                   "the all-gather of the rewards and both MAX all-reduces issued on it; against the plain run on the same box",
+           "one_rank_rccl": {k: one[k] for k in ("value", "ms_per_step", "reward_sha256", "multi_gpu")},
+           "plain": {k: plain[k] for k in ("value", "ms_per_step", "reward_sha256")},
+           "reward_vectors_bit_equal": one["reward_sha256"] == plain["reward_sha256"]},
+          open(os.path.join(P, f"{rnd}_one_rank_rccl.json"), "w"), indent=1)
+shutil.copy(os.path.join(F, "small_call_latency.json"), os.path.join(P, f"{rnd}_small_call_latency.json"))
+# per-config evidence (tools/profile_configs.sh)
+shutil.copy(os.path.join(C, "other_configs.jsonl"), os.path.join(P, f"{rnd}_other_configs.jsonl"))
+for c in ("rope64", "granular", "mixed"):
+    stats(os.path.join(C, f"prof_{c}", "s_kernel_stats.csv"), os.path.join(P, f"{rnd}_{c}_kernel_stats.csv"))
+stats(os.path.join(C, "prof_b3", "s_kernel_stats.csv"), os.path.join(P, f"{rnd}_bf16x3_kernel_stats.csv"))
+for tag, name in (("b3", "bf16x3_pmc_counters.json"), ("gran", "granular_pmc_counters.json")):
+    shutil.copy(os.path.join(C, f"pmc_{tag}_summary.json"), os.path.join(P, f"{rnd}_{name}"))
+print("collected into profiles/", rnd)

@@ -13,14 +13,15 @@ timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_defa
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o d -- python3 $R/bench.py --no-cpu-baseline > $O/prof_default.log 2>&1
-AG_STREAMS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o s -- python3 $R/bench.py --no-cpu-baseline --no-bf16x3 --no-mpc-iter > $O/prof_single.log 2>&1
+# single stream, share_first off: every k_edge_enc launch a full 128-candidate one - the launch shape bench.py's roofline pass times
+AG_STREAMS=1 AG_SHARE_FIRST=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o s -- python3 $R/bench.py --no-cpu-baseline --no-bf16x3 --no-mpc-iter > $O/prof_single.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
-  AG_STREAMS=1 timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python3 $R/bench.py --candidates 256 --steps 1 --warmup 0 --no-cpu-baseline --no-bf16x3 --no-kernel-profile --no-mpc-iter > $O/pmc_$c.log 2>&1
+  AG_STREAMS=1 AG_SHARE_FIRST=0 timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python3 $R/bench.py --candidates 256 --steps 1 --warmup 0 --no-cpu-baseline --no-bf16x3 --no-kernel-profile --no-mpc-iter > $O/pmc_$c.log 2>&1
 done
-AG_STREAMS=1 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -o p -- python3 $R/bench.py --candidates 256 --steps 1 --warmup 0 --no-cpu-baseline --no-bf16x3 --no-kernel-profile --no-mpc-iter > $O/pmc_sq.log 2>&1
+AG_STREAMS=1 AG_SHARE_FIRST=0 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -o p -- python3 $R/bench.py --candidates 256 --steps 1 --warmup 0 --no-cpu-baseline --no-bf16x3 --no-kernel-profile --no-mpc-iter > $O/pmc_sq.log 2>&1
 cd $R
-for k in k_edge_enc "k_node_prop<false>" "k_node_prop<true>"; do
-  n=$(echo $k | tr -d '<>' )
+for k in "k_edge_enc<4>" "k_node_prop<false, false>" "k_node_prop<true, false>"; do
+  n=$(echo $k | sed 's/<4>//; s/<false, false>/false/; s/<true, false>/true/')
   python tools/pmc_traffic.py "$k" $O/traffic_$n.json $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv > /dev/null
 done
 python - <<'PY'
@@ -41,9 +42,14 @@ out={n:{c:sum(v)/len(v) for c,v in cs.items()} for n,cs in acc.items()}
 json.dump(out,open(f"{O}/pmc_summary.json","w"),indent=1)
 for n,cs in out.items(): print(n,{c:round(v) for c,v in cs.items()})
 PY
-timeout -k 10 300 python tools/bench_configs.py > $O/other_configs.jsonl 2> $O/other_configs.err
-timeout -k 10 300 python tools/bench_planner.py > $O/planner_configs.jsonl 2> $O/planner_configs.err
+timeout -k 10 400 python tools/bench_planner.py > $O/planner_configs.jsonl 2> $O/planner_configs.err
+AG_SHARE_FIRST=0 timeout -k 10 300 python tools/bench_planner.py --modes chunked --sorts 1 > $O/planner_configs_share0.jsonl 2> $O/planner_configs_share0.err
+# the RCCL calls with a world of one rank (bench.py AG_BENCH_FORCE_DIST=1): reward hash equal to the plain line's
+AG_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-bf16x3 --no-mpc-iter --no-kernel-profile > $O/bench_one_rank_rccl.json 2> $O/bench_one_rank_rccl.err
+timeout -k 10 300 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-bf16x3 --no-mpc-iter --no-kernel-profile > $O/bench_plain_short.json 2> $O/bench_plain_short.err
 timeout -k 10 120 python tools/trace_mpc_iter.py > $O/small_call_latency.json 2> /dev/null
+cd $R
+bash tools/profile_configs.sh > $O/profile_configs.log 2>&1 || tail -20 $O/profile_configs.log
 find $O -type f \( -name '*kernel_trace*' -o -name '*.db' -o -name '*agent_info*' -o -name '*counter_collection*' \) -delete
 du -sh $O
 cat $O/bench_default.json | cut -c1-400
