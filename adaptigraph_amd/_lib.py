@@ -32,7 +32,7 @@ EXPORTS = ["ag_abi_version", "ag_ctx_create", "ag_ctx_destroy", "ag_last_error",
            "ag_ctx_set_option", "ag_ctx_get_option", "ag_ctx_rollout_counts", "ag_rollout_actions", "ag_ctx_share_counts", "ag_ctx_launch_counts"]
 
 OPTIONS = ["streams", "chunk", "latency", "ragged", "ell_graph", "self_dedupe", "repeat_sort", "edge_wgs", "edge_block_min",
-           "enc_persist", "stagger_us", "device_decode", "zigzag", "share_first"]
+           "enc_persist", "stagger_us", "device_decode", "zigzag", "share_first", "share_prefix"]
 
 
 class AgDims(C.Structure):

@@ -66,6 +66,7 @@ struct ag_ctx {
     long long fwd_executed = 0, fwd_needed = 0;       // candidate-forwards of the last rollout call (ag_ctx_rollout_counts)
     char* d_plan = nullptr; size_t plan_cap = 0;      // device-planned rollouts (ag_rollout_actions): decoded tool keypoints,
     int* d_plan_sums = nullptr; int plan_sums_n = 0;  // repeats, launch order and per-step live counts; sums pending a read-back
+    int* h_rep_pin = nullptr; size_t rep_pin_cap = 0;     // pinned: [forwards left | action_repeat] of a prefix-sharing call (contact plan)
     int* h_plan_max = nullptr; size_t plan_max_cap = 0;   // pinned host copy of RollPlan::maxrep of the call being enqueued
     hipEvent_t ev_plan = nullptr;                       // fires when that copy has landed
     long long steps_enqueued = 0, steps_bound = 0;      // model forwards (per chunk) enqueued by the last rollout call / what the bound alone gives
@@ -106,6 +107,7 @@ const OptName kOptions[] = {
     {"device_decode", "AG_DEVICE_DECODE", &Options::device_decode, false, -1, 1},
     {"zigzag", "AG_ZIGZAG", &Options::zigzag, false, 0, 1},
     {"share_first", "AG_SHARE_FIRST", &Options::share_first, false, -1, 1},
+    {"share_prefix", "AG_SHARE_PREFIX", &Options::share_prefix, false, -1, 1},
 };
 void options_from_env(Options& o) {   // values from the environment are clamped into the option's range
     for (const OptName& n : kOptions)
@@ -516,6 +518,7 @@ int ag_ctx_destroy(ag_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->h_plan_max) (void)hipHostFree(c->h_plan_max);
+    if (c->h_rep_pin) (void)hipHostFree(c->h_rep_pin);
     for (int i = 1; i < ag_ctx::kMaxStreams; ++i) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->aux_stream[i]) (void)hipStreamDestroy(c->aux_stream[i]);
@@ -898,7 +901,26 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     int *pl_repeat = nullptr, *pl_cand = nullptr, *pl_live = nullptr, *pl_rows = nullptr, *pl_sums = nullptr;
     float *pl_xz = nullptr, *pl_delta = nullptr;
     c->d_plan_sums = nullptr;
-    if (!dev_plan) {
+    // Contact-free prefix (Options::share_prefix; RollArgs::start).  Without connect_tools_all a tool acts on the object only
+    // through the edges it takes part in, and it takes part in none while no object particle is inside its radius.  Until then a
+    // candidate's object particles evolve exactly - bit for bit: a row's result does not depend on the rest of its batch - like
+    // the start state WITHOUT a tool.  That base rollout is computed once per call (one candidate, tool parked out of reach);
+    // k_contact_plan replays every candidate's tool along it and finds the forward of its first contact; a candidate is then
+    // stepped only from there on (its slot starts from the base state and history of that step), and one that never touches
+    // takes the base state of its last step.  The reference's planner samples its pushes uniformly over the workspace
+    // (plan_utils.py:48-50 with planning/*.yaml:28-29): most of them never reach the object.  Look-ahead step 0 only (later
+    // steps start from per-candidate states).  The contact plan decides the launch sizes, so the call waits for it once - the GPU
+    // is busy with the base rollout meanwhile.
+    bool prefix = c->opt.share_prefix != 0 && p->y_mode == 0 && !d_obj_mask && !p->connect_tools_all && p->M <= 8;
+    if (c->opt.share_prefix < 0 && (p->B < 64 || (long)p->B * N < 32768)) prefix = false;
+    int R_base = 0;                                          // steps of the base rollout = the largest repeat of look-ahead step 0
+    if (prefix) {
+        if (dev_plan) R_base = R;
+        else for (int b = 0; b < p->B; ++b) R_base = std::max(R_base, (int)h_repeat[(size_t)b * p->H]);
+        if (R_base < 1) prefix = false;
+    }
+    // host plan: repeat counts -> per chunk and look-ahead step the launch order (descending repeat, stable), both uploaded
+    auto host_plan = [&](const int32_t* rep_src) -> int {
         if (c->repeat_cap < 2 * nrep) {
             if (c->d_repeat) HIPCHK(c, hipFree(c->d_repeat));
             c->d_repeat = nullptr; c->repeat_cap = 0;
@@ -906,7 +928,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             c->repeat_cap = 2 * nrep;
         }
         c->h_repeat.resize(2 * nrep);
-        std::copy(h_repeat, h_repeat + nrep, c->h_repeat.begin());
+        std::copy(rep_src, rep_src + nrep, c->h_repeat.begin());
         h_repeat = c->h_repeat.data();
         h_cand = c->h_repeat.data() + nrep;                  // [li][slot] -> candidate
         for (int li = 0; li < p->H; ++li)
@@ -918,6 +940,11 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
                     std::stable_sort(seg, seg + nb, [&](int x, int y) { return h_repeat[(size_t)x * p->H + li] > h_repeat[(size_t)y * p->H + li]; });
             }
         HIPCHK(c, hipMemcpyAsync(c->d_repeat, h_repeat, 2 * nrep * 4, hipMemcpyHostToDevice, st));
+        return AG_OK;
+    };
+    if (!dev_plan) {
+        rc = host_plan(h_repeat);                            // (prefix sharing plans again, with the forwards that are left)
+        if (rc) return rc;
         c->fwd_executed = 0; c->fwd_needed = 0;
         for (size_t i = 0; i < nrep; ++i) c->fwd_needed += std::max(0, h_repeat[i]);
     } else {
@@ -963,6 +990,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         c->d_plan_sums = pl_sums; c->plan_sums_n = n_chunks_all * p->H;
         c->fwd_executed = -1; c->fwd_needed = -1;
     }
+    const bool loop_dev = dev_plan && !prefix;               // the enqueue loop reads its live counts from the device plan's tables
 
     // Shared first forward (Options::share_first).  dynamics() broadcasts ONE start state to all candidates with a constant
     // history (forward_dynamics.py:25), then builds and encodes every candidate's graph separately (:125, model.py:303).  At
@@ -974,7 +1002,8 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     // there (k_ell_index: send_pk); per candidate only the edges with a tool at either end are encoded.  Bit-identical: a
     // row's chain does not depend on the lane / workgroup / launch that computes it.
     const int kb = std::min(p->N_o, p->topk);
-    bool share = c->opt.share_first != 0 && p->y_mode == 0 && !d_obj_mask && ell_full && p->topk < p->N_o && k <= 255;
+    bool share = c->opt.share_first != 0 && p->y_mode == 0 && !d_obj_mask && ell_full && p->topk < p->N_o && k <= 255 &&
+                 !prefix;   // (with the prefix sharing a candidate's first own forward is no longer the start state's)
     if (c->opt.share_first < 0 && p->B < 8) share = false;   // a handful of candidates: the base build costs more than it saves
     {   // launches small enough for the latency-mode propagate chains (ag_lat.hip) keep their own C rows
         GraphBufs gt{};
@@ -985,8 +1014,9 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     const int base_slices = pick_slices(c, 1, p->N_o);
     const size_t base_bytes = !share ? 0 : (size_t)base_cap * (NFP + 3) * 4 + (size_t)p->N_o * (NODE_IN + F15_PITCH + 2) * 4 +
                                            2 * (size_t)p->N_o + (size_t)(base_slices + 8) * 4 + 24 * 256;
+    const size_t prefix_bytes = !prefix ? 0 : ((size_t)(R_base + 1) * (p->N_o * 3 + 1) + 2 * nrep + p->B + 5 * p->M + 64) * 4 + 16 * 256;
     const size_t wb = work_bytes(Ba, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
-    rc = ensure_slab(c, wb * ns + base_bytes);
+    rc = ensure_slab(c, wb * ns + base_bytes + prefix_bytes);
     if (rc) return rc;
     Work ws[ag_ctx::kMaxStreams] = {};
     for (int i = 0; i < ns; ++i) {
@@ -1023,6 +1053,83 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         rc = run_edge_chain(c, gb, st);
         if (rc) return rc;
         base_send = b_send; base_deg = b_deg; C_share = b_C; c->d_share_nns = b_n_ns;
+    }
+    const int* d_start = nullptr; const float* d_base_states = nullptr; const float* d_base_y = nullptr;
+    if (prefix) {
+        Slab& sl = c->slab;
+        float* b_states = sl.take<float>((size_t)(R_base + 1) * p->N_o * 3);
+        float* b_y = sl.take<float>(R_base + 1);
+        int* b_rep_eff = sl.take<int>(nrep); int* b_start = sl.take<int>(p->B);
+        float* b_eef = sl.take<float>((size_t)5 * p->M);   // parked tool: xz (M,2), delta (M,3)
+        int* b_zero = sl.take<int>(1);
+        if (sl.used > sl.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
+        std::vector<float> park((size_t)5 * p->M, 0.0f);
+        for (int m = 0; m < 2 * p->M; ++m) park[m] = 1.0e6f;  // out of every particle's reach; delta 0: it stays there
+        HIPCHK(c, hipMemcpyAsync(b_eef, park.data(), park.size() * 4, hipMemcpyHostToDevice, st));   // (pageable: copied before return)
+        HIPCHK(c, hipMemsetAsync(b_zero, 0, 4, st));
+        HIPCHK(c, hipMemcpyAsync(b_states, d_state0, (size_t)p->N_o * 3 * 4, hipMemcpyDeviceToDevice, st));   // S_0
+        {   // ---- the base rollout: one candidate on workspace 0, R_base forwards, every state recorded
+            Work& w = ws[0];
+            GraphBufs g = w.g;
+            g.B = 1; g.n_p = p->N_o; g.n_his = n_his; g.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
+            if (dedupe) {
+                g.c_self = c->d_cself; g.ns_edge = w.ns_edge; g.n_ns = w.n_ns; g.self_row = (long)Ba * edge_cap;
+                HIPCHK(c, hipMemcpyAsync(w.g.C + (size_t)g.self_row * NFP, c->d_cself, 2 * NFP * 4, hipMemcpyDeviceToDevice, st));
+            }
+            RollArgs ra{};
+            ra.B = 1; ra.B_slots = 1; ra.N_o = p->N_o; ra.M = p->M; ra.H = 1; ra.y_mode = 0; ra.b0 = 0; ra.li = 0; ra.ai = 0;
+            ra.grip = p->gripper_offset; ra.grip_on = p->gripper_enable; ra.phys = p->physics_param; ra.phys_vec = d_phys_vec;
+            ra.state0 = d_state0; ra.state0_batched = 0; ra.eef_xz = b_eef; ra.eef_delta = b_eef + 2 * p->M; ra.repeat = b_zero;
+            ra.write_obj_cls = 1; ra.all_states = b_states; ra.all_y = b_y;
+            EdgeArgs ea{};
+            ea.pos = w.r.hist + (size_t)(n_his - 1) * N * 3; ea.pos_bstride = (long)n_his * N * 3;
+            ea.mask = w.r.mask; ea.tool = w.r.tool; ea.thr = p->adj_thresh; ea.B = 1; ea.N = N; ea.topk = p->topk; ea.cta = 0;
+            ea.edge_cap = edge_cap; ea.slices = slices; ea.ell = w.ell; ea.deg = w.deg; ea.slice_tot = w.slice_tot; ea.cta_flag = w.cta_flag;
+            ea.recv = w.recv; ea.send = w.send; ea.row_ptr = w.row_ptr; ea.n_edges = w.n_edges; ea.overflow = d_overflow_flag;
+            ea.max_nR = p->max_nR; ea.zero_on_overflow = 1; ea.block_min_rows = c->opt.edge_block_min;
+            if (ell_full) {
+                ea.ell_full = 1; ea.ell = w.send; ea.ell_stride = k + p->M; ea.ell_bstride = edge_cap; ea.ns_edge = w.ns_edge; ea.n_ns = w.n_ns;
+                g.deg = w.deg; g.ell_stride = k + p->M;
+            }
+            w.r.ragged = 0; w.r.clamp = c->dims.motion_clamp;
+            { Scoped sc(c, FAM_ROLL_INIT); HIPCHK(c, launch_roll_init(ra, w.r, g, st)); }
+            { Scoped sc(c, FAM_NODE_ENC); HIPCHK(c, launch_node_enc(c->d_w, g, 0, 2L * p->N_o + p->M, st)); }
+            for (int ai = 1; ai <= R_base; ++ai) {
+                HIPCHK(c, launch_edge_build(ea, st, prof_mark, c));
+                if (g.ns_edge && !ell_full) { Scoped sc(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, 1, N, edge_cap, w.ns_edge, w.n_ns, nullptr, st)); }
+                rc = run_model(c, g, w.r.pred, w.r.motion, st);
+                if (rc) return rc;
+                ra.ai = ai;
+                { Scoped sc(c, FAM_ROLL_UPDATE); HIPCHK(c, launch_roll_update(ra, w.r, g, st)); }
+            }
+        }
+        // ---- contact plan -> forwards left per candidate, back on the host (the one wait of a prefix-sharing call)
+        const int* d_rep_orig = dev_plan ? pl_repeat : c->d_repeat;
+        ContactPlan cp{};
+        cp.base_states = b_states; cp.base_y = b_y; cp.R = R_base; cp.eef_xz = d_eef_xz; cp.eef_delta = d_eef_delta; cp.repeat = d_rep_orig;
+        cp.B = p->B; cp.H = p->H; cp.N_o = p->N_o; cp.M = p->M; cp.thr = p->adj_thresh; cp.rep_eff = b_rep_eff; cp.start = b_start;
+        cp.state_seqs = d_state_seqs;
+        HIPCHK(c, launch_contact_plan(cp, st));
+        if (c->rep_pin_cap < 2 * nrep) {
+            if (c->h_rep_pin) HIPCHK(c, hipHostFree(c->h_rep_pin));
+            c->h_rep_pin = nullptr; c->rep_pin_cap = 0;
+            HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_rep_pin), (2 * nrep + 64) * 4, hipHostMallocDefault));
+            c->rep_pin_cap = 2 * nrep + 64;
+        }
+        if (!c->ev_plan) HIPCHK(c, hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
+        HIPCHK(c, hipMemcpyAsync(c->h_rep_pin, b_rep_eff, nrep * 4, hipMemcpyDeviceToHost, st));
+        if (dev_plan) HIPCHK(c, hipMemcpyAsync(c->h_rep_pin + nrep, pl_repeat, nrep * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipEventRecord(c->ev_plan, st));
+        HIPCHK(c, hipEventSynchronize(c->ev_plan));
+        if (dev_plan) {
+            c->fwd_needed = 0;
+            for (size_t i = 0; i < nrep; ++i) c->fwd_needed += std::min(std::max(0, c->h_rep_pin[nrep + i]), R);
+            c->d_plan_sums = nullptr;
+        }
+        c->fwd_executed = R_base;                             // the base rollout's forwards
+        rc = host_plan(c->h_rep_pin);                         // launch order and sizes from the forwards that are LEFT
+        if (rc) return rc;
+        d_start = b_start; d_base_states = b_states; d_base_y = b_y;
     }
     hipStream_t streams[ag_ctx::kMaxStreams] = {st, st, st, st};
     if (ns > 1) {
@@ -1067,7 +1174,8 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         ra.B = nb; ra.B_slots = nb; ra.N_o = p->N_o; ra.M = p->M; ra.H = p->H; ra.y_mode = p->y_mode; ra.b0 = b0;
         ra.grip = p->gripper_offset; ra.grip_on = p->gripper_enable; ra.phys = p->physics_param; ra.phys_vec = d_phys_vec;
         ra.state0 = d_state0; ra.state0_batched = p->y_mode == 1; ra.obj_mask = d_obj_mask;
-        ra.eef_xz = d_eef_xz; ra.eef_delta = d_eef_delta; ra.repeat = dev_plan ? pl_repeat : c->d_repeat; ra.state_seqs = d_state_seqs;
+        ra.eef_xz = d_eef_xz; ra.eef_delta = d_eef_delta; ra.repeat = loop_dev ? pl_repeat : c->d_repeat; ra.state_seqs = d_state_seqs;
+        ra.start = d_start; ra.base_states = d_base_states; ra.base_y = d_base_y;
         EdgeArgs ea{};
         ea.pos = w.r.hist + (size_t)(n_his - 1) * N * 3; ea.pos_bstride = (long)n_his * N * 3;   // the newest frame
         ea.mask = w.r.mask; ea.tool = w.r.tool; ea.thr_vec = nullptr; ea.thr = p->adj_thresh;
@@ -1088,13 +1196,14 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             g.rowlist = w.rowlist; g.n_rows = w.n_rows + nb;
         }
         for (int li = 0; li < p->H; ++li) {
-            const int* seg = dev_plan ? nullptr : h_cand + (size_t)li * p->B + b0;   // slot -> candidate of this chunk and look-ahead step
-            int max_rep = dev_plan ? R : 0;                  // device plan: the caller's bound; steps past a chunk's own maximum find no live slot
-            if (!dev_plan) for (int b = 0; b < nb; ++b) max_rep = std::max(max_rep, h_repeat[(size_t)seg[b] * p->H + li]);
+            const int* seg = loop_dev ? nullptr : h_cand + (size_t)li * p->B + b0;   // slot -> candidate of this chunk and look-ahead step
+            int max_rep = loop_dev ? R : 0;                  // device plan: the caller's bound; steps past a chunk's own maximum find no live slot
+            if (!loop_dev) for (int b = 0; b < nb; ++b) max_rep = std::max(max_rep, h_repeat[(size_t)seg[b] * p->H + li]);
+            if (max_rep == 0 && !loop_dev) continue;          // nothing of this chunk is stepped in this look-ahead step
             ra.li = li; ra.ai = 0; ra.B = nb; ra.live = nullptr;
-            ra.cand = dev_plan ? pl_cand + (size_t)li * p->B + b0 : sort_on ? c->d_repeat + nrep + (size_t)li * p->B + b0 : nullptr;
-            const int* live_row = dev_plan ? pl_live + ((size_t)ci * p->H + li) * (R + 2) : nullptr;
-            const int* rows_row = dev_plan ? pl_rows + ((size_t)ci * p->H + li) * (R + 2) : nullptr;
+            ra.cand = loop_dev ? pl_cand + (size_t)li * p->B + b0 : sort_on ? c->d_repeat + nrep + (size_t)li * p->B + b0 : nullptr;
+            const int* live_row = loop_dev ? pl_live + ((size_t)ci * p->H + li) * (R + 2) : nullptr;
+            const int* rows_row = loop_dev ? pl_rows + ((size_t)ci * p->H + li) * (R + 2) : nullptr;
             // masked variant: the object rows depend on nothing per-candidate either (both validity variants are
             // tabulated), so they are encoded once per call and workspace; tool rows once per look-ahead step
             ra.write_obj_cls = obj_cls_ready[ci % ns] ? 0 : 1;
@@ -1107,7 +1216,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             int n_live = nb;
             c->steps_bound += max_rep;
             for (int ai = 1; ai <= max_rep; ++ai) {           // forward_dynamics.py:156
-                if (dev_plan) {
+                if (loop_dev) {
                     // past this chunk's own maximum no slot is live: stop as soon as the plan's maxima are known (no waiting)
                     if (!plan_landed && ai > 1) {
                         if (hipEventQuery(c->ev_plan) == hipSuccess) plan_landed = true;
@@ -1116,7 +1225,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
                     if (plan_landed && ai > c->h_plan_max[(size_t)ci * p->H + li]) break;
                 }
                 ++c->steps_enqueued;
-                if (dev_plan) {   // grids cover the whole chunk; the kernels read how many slots are live from the plan's table
+                if (loop_dev) {   // grids cover the whole chunk; the kernels read how many slots are live from the plan's table
                     ea.live = live_row + ai; ra.live = live_row + ai; g.n_rows = rows_row + ai;
                 } else {
                     if (sort_on) while (n_live > 0 && h_repeat[(size_t)seg[n_live - 1] * p->H + li] < ai) --n_live;   // descending order: a prefix

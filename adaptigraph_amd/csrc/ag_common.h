@@ -88,6 +88,10 @@ struct Options {
                               //                     ag_rollout_actions (-1: when the task config bounds the repeat, 0 never, 1 always).
                               //                     The one switch that is NOT bit-neutral: cos/sin of the decode are then the device's,
                               //                     so action_seqs agrees with a host decode to ~1e-7, not bit for bit
+    int share_prefix = -1;    // [AG_SHARE_PREFIX]   contact-free prefix of look-ahead step 0 (connect_tools_all off): candidates whose tool has
+                              //                     not touched the object yet follow ONE tool-free base rollout (-1: batches of >= 64
+                              //                     candidates and >= 32768 rows, 0 never, 1 whenever possible).  Waits once per call
+                              //                     for the contact plan (the GPU is busy with the base rollout meanwhile)
     int share_first = -1;     // [AG_SHARE_FIRST]    first forward of a dynamics() call: the relation encoder runs ONCE over the
                               //                     object-object edges of the start state's tool-free graph and every candidate reads
                               //                     those C rows (-1: batches of 8 candidates or more, 0 never, 1 whenever possible)
@@ -237,7 +241,30 @@ struct RollArgs {
     const int* cand;                          // null, or (B,) device: slot b of this chunk holds candidate cand[b] of the full
                                               // batch (repeat-sorted launch order); null = candidate b0 + b
     float* state_seqs;                        // (Bfull,H,N_o,3)
+    // ---- contact-free prefix (Options::share_prefix; look-ahead step 0 of dynamics() only).  Until a candidate's tool first
+    // comes within the radius of an object particle its graph holds no tool edge, so its object particles evolve exactly as
+    // in the tool-free BASE rollout of the start state, which is computed once per call: base_states (R+1, N_o, 3) = S_0
+    // (the start state) .. S_R, base_y (R+1) = the tool height the reference derives from S_s (forward_dynamics.py:40,163).
+    // start (Bfull,) = base step a candidate's own stepping starts from (its first contact is at forward start + 1); k_roll_init
+    // then fills the slot's history with S_(start-3) .. S_start and the tool positions replayed up to there, and `repeat`
+    // holds the forwards that are LEFT.  Null: every candidate starts from the start state.
+    const float* base_states; const float* base_y; const int* start;
+    // the base rollout itself: every step's prediction and tool height are recorded (null for ordinary candidates)
+    float* all_states; float* all_y;
 };
+// Contact plan of the prefix sharing (ag_graph.hip: k_contact_plan).  Per candidate: replay the tool keypoints along the base
+// rollout (x, z advance by fp32 adds exactly as k_roll_update advances them; y = base_y) and find the first forward whose graph
+// would hold a tool-object pair inside the radius - the edge builder's own arithmetic (ag_edges.hip: dist_exact, (dis - thr^2) < 0),
+// so "no contact" is exactly "no tool edge in either direction, whatever top-k keeps".
+struct ContactPlan {
+    const float* base_states; const float* base_y; int R;   // S_0..S_R, base_y[0..R]
+    const float* eef_xz; const float* eef_delta; const int* repeat;   // (B,H,M,2), (B,H,M,3), (B,H): look-ahead step 0 is read
+    int B, H, N_o, M; float thr;
+    int* rep_eff;               // (B,H) out: forwards left per look-ahead step (step 0: repeat - first contact + 1, or 0; others: repeat)
+    int* start;                 // (B,) out: base step the candidate starts from (0 when it never touches or touches at once)
+    float* state_seqs;          // (B,H,N_o,3): candidates that never touch get S_repeat at look-ahead step 0 here
+};
+hipError_t launch_contact_plan(const ContactPlan& p, hipStream_t st);
 // cost kernels (ag_cost.hip)
 hipError_t launch_chamfer(const float* x, const float* y, const uint8_t* xm, const uint8_t* ym, int R, int N, int M,
                           int By, float* out, hipStream_t st);

@@ -120,11 +120,22 @@ __global__ __launch_bounds__(RT) void k_roll_init(RollDev d) {
     const RollArgs& a = d.a;
     const int b = blockIdx.x, bg = a.cand ? a.cand[b] : a.b0 + b, tid = threadIdx.x;
     const int N = a.N_o + a.M;
-    const float* src = a.li == 0 ? (a.state0_batched ? a.state0 + (long)bg * a.N_o * 3 : a.state0)
+    // Contact-free prefix (RollArgs::start): the slot starts from the BASE rollout's state `s0` - the candidate's tool touches
+    // the object first at forward s0 + 1 - with the history the reference would hold there: object frames S_(s0-NH+1) .. S_s0
+    // (clamped at the start state, :25), tool frames replayed with the very additions k_roll_update performs.
+    const bool pre = a.start != nullptr && a.li == 0;
+    const int s0 = pre ? a.start[bg] : 0;
+    const float* src = pre ? a.base_states + (long)s0 * a.N_o * 3
+                     : a.li == 0 ? (a.state0_batched ? a.state0 + (long)bg * a.N_o * 3 : a.state0)
                                  : a.state_seqs + ((long)bg * a.H + (a.li - 1)) * a.N_o * 3;
     const uint8_t* om = a.obj_mask ? a.obj_mask + (long)bg * a.N_o : nullptr;
-    float y = tool_y(src, om, a.N_o, a.y_mode, red, redi);
-    if (a.grip_on) y = y + a.grip;                           // :80-81
+    float y;
+    if (pre) y = a.base_y[s0];                               // = tool_y(S_s0) (+ gripper offset), recorded by the base rollout
+    else {
+        y = tool_y(src, om, a.N_o, a.y_mode, red, redi);
+        if (a.grip_on) y = y + a.grip;                       // :80-81
+    }
+    if (a.all_y && tid == 0) a.all_y[0] = y;                 // the base rollout records its tool heights
     int count = a.N_o;
     if (om) {                                                // first-`count` rows carry p_instance (:294-300)
         int c = 0;
@@ -148,13 +159,45 @@ __global__ __launch_bounds__(RT) void k_roll_init(RollDev d) {
             act[0] = dl[0]; act[1] = dl[1]; act[2] = dl[2];
         }
         const long row = (long)b * N + i;
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) d.hist[(((long)b * NH + h) * N + i) * 3 + c] = p[c];
         float* f = d.feat12 + row * FP;
 #pragma unroll
         for (int c = 0; c < FP; ++c) f[c] = 0.0f;            // identical frames: residuals are exactly 0 (and the row's pad)
+        if (!pre || s0 == 0) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d.hist[(((long)b * NH + h) * N + i) * 3 + c] = p[c];
+        } else {
+            float fr[NH][3];                                 // frame k = time max(0, s0 - (NH-1-k))
+            if (!is_tool) {
+#pragma unroll
+                for (int k = 0; k < NH; ++k) {
+                    const float* sp = a.base_states + ((long)max(0, s0 - (NH - 1 - k)) * a.N_o + i) * 3;
+                    fr[k][0] = sp[0]; fr[k][1] = sp[1]; fr[k][2] = sp[2];
+                }
+            } else {
+                // time 0 = the keypoint of the decoded action (p holds it with the height of time s0: x, z are what count);
+                // every step adds the per-step delta (forward_dynamics.py:164) - the same fp32 additions, in the same order
+                float x = p[0], z = p[2];
+                const int t_first = s0 - (NH - 1);
+#pragma unroll
+                for (int k = 0; k < NH; ++k) if (t_first + k <= 0) { fr[k][0] = x; fr[k][1] = a.base_y[0]; fr[k][2] = z; }
+                for (int t = 1; t <= s0; ++t) {
+                    x = x + act[0]; z = z + act[2];
+#pragma unroll
+                    for (int k = 0; k < NH; ++k) if (t_first + k == t) { fr[k][0] = x; fr[k][1] = a.base_y[t]; fr[k][2] = z; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NH; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d.hist[(((long)b * NH + k) * N + i) * 3 + c] = fr[k][c];
+#pragma unroll
+            for (int k = 0; k < NH - 1; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) f[3 * k + c] = fr[k + 1][c] - fr[k][c];        // model.py:156, as k_roll_update forms it
+            p[0] = fr[NH - 1][0]; p[1] = fr[NH - 1][1]; p[2] = fr[NH - 1][2];
+        }
         f[3 * (NH - 1)] = p[0]; f[3 * (NH - 1) + 1] = p[1]; f[3 * (NH - 1) + 2] = p[2];
         const bool ov = is_tool ? false : (om ? om[i] != 0 : true);
         float* n = d.node_in + row * NODE_IN;
@@ -215,6 +258,11 @@ __global__ __launch_bounds__(RT) void k_roll_update(RollDev d) {
     }
     float y = tool_y(pred, om, a.N_o, a.y_mode, red, redi);  // :163 / :359
     if (a.grip_on) y = y + a.grip;                           // :167-168
+    if (a.all_states) {                                      // the base rollout of the prefix sharing: S_ai and its tool height
+        float* out = a.all_states + (long)a.ai * a.N_o * 3;
+        for (int k = tid; k < a.N_o * 3; k += RT) out[k] = pred[k];
+        if (tid == 0) a.all_y[a.ai] = y;
+    }
     for (int i = tid; i < N; i += RT) {
         const long row = (long)b * N + i;
         float h[NH][3];
@@ -399,6 +447,54 @@ hipError_t launch_roll_plan(const RollPlan& p, hipStream_t st) {
     if (p.max_repeat > PLAN_MAXR) return hipErrorInvalidValue;
     const int n_chunks = (p.B + p.Bc - 1) / p.Bc;
     hipLaunchKernelGGL(k_roll_plan, dim3(n_chunks * p.H), dim3(64), 0, st, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ contact-free prefix
+// See ContactPlan (ag_common.h).  One workgroup per candidate.  The pair test is the edge builder's (ag_edges.hip: dist_exact,
+// pair_within): dis = ((dx*dx + dy*dy) + dz*dz) with separate roundings, adjacent <=> (dis - thr*thr) < 0 (graph.py:248-267).
+__device__ __forceinline__ float contact_dis(float xi, float yi, float zi, float xj, float yj, float zj) {
+    const float dx = __fsub_rn(xi, xj), dy = __fsub_rn(yi, yj), dz = __fsub_rn(zi, zj);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+constexpr int CT = 256;
+__global__ __launch_bounds__(CT) void k_contact_plan(ContactPlan p) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int li = 1 + tid; li < p.H; li += CT) p.rep_eff[(long)b * p.H + li] = p.repeat[(long)b * p.H + li];
+    const int rep = min(max(p.repeat[(long)b * p.H], 0), p.R);
+    const float thr2 = __fmul_rn(p.thr, p.thr);
+    float tx[8], tz[8], dx[8], dz[8];
+    for (int m = 0; m < p.M; ++m) {
+        const float* xz = p.eef_xz + ((long)b * p.H * p.M + m) * 2;          // look-ahead step 0
+        const float* dl = p.eef_delta + ((long)b * p.H * p.M + m) * 3;
+        tx[m] = xz[0]; tz[m] = xz[1]; dx[m] = dl[0]; dz[m] = dl[2];
+    }
+    int d = 0;
+    for (int ai = 1; ai <= rep; ++ai) {                      // the graph of forward ai: objects S_(ai-1), tool after ai-1 advances
+        const float* S = p.base_states + (long)(ai - 1) * p.N_o * 3;
+        const float ty = p.base_y[ai - 1];
+        int hit = 0;
+        for (int i = tid; i < p.N_o; i += CT) {
+            const float x = S[3 * i], y = S[3 * i + 1], z = S[3 * i + 2];
+            for (int m = 0; m < p.M; ++m)
+                hit |= __fsub_rn(contact_dis(x, y, z, tx[m], ty, tz[m]), thr2) < 0.0f ? 1 : 0;
+        }
+        if (__syncthreads_or(hit)) { d = ai; break; }
+        for (int m = 0; m < p.M; ++m) { tx[m] = tx[m] + dx[m]; tz[m] = tz[m] + dz[m]; }   // forward_dynamics.py:164
+    }
+    if (tid == 0) {
+        p.rep_eff[(long)b * p.H] = d ? rep - d + 1 : 0;
+        p.start[b] = d ? d - 1 : 0;
+    }
+    if (!d && rep >= 1) {                                    // never touched: the capture of forward `rep` is the base state S_rep
+        const float* S = p.base_states + (long)rep * p.N_o * 3;
+        float* out = p.state_seqs + (long)b * p.H * p.N_o * 3;
+        for (int k = tid; k < p.N_o * 3; k += CT) out[k] = S[k];
+    }
+}
+hipError_t launch_contact_plan(const ContactPlan& p, hipStream_t st) {
+    if (p.M > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_contact_plan, dim3(p.B), dim3(CT), 0, st, p);
     return hipGetLastError();
 }
 

@@ -133,9 +133,17 @@ int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
  *                                         candidates, forward_dynamics.py:25): the relation encoder runs once over the
  *                                         object-object edges of the start state's tool-free graph, every candidate reads those
  *                                         C rows; -1 = batches of >= 8 candidates (default), 0 never, 1 whenever possible
+ *   "share_prefix"   [AG_SHARE_PREFIX]    contact-free prefix of look-ahead step 0 (y_mode 0, connect_tools_all off): a candidate whose
+ *                                         tool has not yet come within adj_thresh of an object particle has no tool edge, so its
+ *                                         object particles evolve exactly like the start state without a tool.  That base rollout runs
+ *                                         once per call; every candidate is stepped only from its first contact on and one that never
+ *                                         touches takes the base state of its last step (same bits as stepping it).  -1 = batches of
+ *                                         >= 64 candidates and >= 32768 particle rows (default), 0 never, 1 whenever possible.  The call
+ *                                         WAITS once for the contact plan (the GPU is running the base rollout meanwhile), so
+ *                                         ag_rollout_async / ag_rollout_actions are then not purely asynchronous
  * Unknown names and values outside an option's range return AG_ERR_INVALID (ranges: streams 0..4, chunk 0..2^20, latency -1..1,
  * the 0/1 switches 0..1, edge_wgs 1..65536, edge_block_min -1..INT32_MAX, enc_persist 0..2^20, stagger_us 0..1000,
- * device_decode -1..1, share_first -1..1). */
+ * device_decode -1..1, share_first -1..1, share_prefix -1..1). */
 int ag_ctx_set_option(ag_ctx* ctx, const char* name, int32_t value);
 int ag_ctx_get_option(ag_ctx* ctx, const char* name, int32_t* out_value);
 
@@ -143,7 +151,9 @@ int ag_ctx_get_option(ag_ctx* ctx, const char* name, int32_t* out_value);
  * launches of the candidates each model forward was launched over) and needed (sum of action_repeat over the batch).  With
  * the repeat-aware launch order (default; masked batches included) the two are equal; with "repeat_sort" 0 every candidate of
  * a launch chunk is stepped to the chunk's maximum, as the reference steps the whole batch to the batch maximum
- * (forward_dynamics.py:156-161).  After ag_rollout_actions the call waits for the device (the sums live there). */
+ * (forward_dynamics.py:156-161); with "share_prefix" active executed (which then includes the base rollout's forwards) is
+ * SMALLER than needed: the forwards before a candidate's first contact are the base rollout's.  After an ag_rollout_actions
+ * call without prefix sharing the call waits for the device (the sums live there). */
 int ag_ctx_rollout_counts(ag_ctx* ctx, int64_t* out_executed, int64_t* out_needed);
 
 /* Model forwards (per launch chunk and look-ahead step) ENQUEUED by the LAST ag_rollout / ag_rollout_async /

@@ -851,7 +851,7 @@ def test_repeat_sorted_launch_order_is_bit_identical_and_runs_no_surplus_forward
     outs = {}
     for streams in (1, 2):
         for chunk in (0, 37):
-            with eng.options(streams=streams):
+            with eng.options(streams=streams, share_prefix=0):       # (this test counts the forwards of the repeat-aware order alone)
                 eng.set_chunk(chunk)
                 try:
                     got = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]
@@ -941,7 +941,10 @@ def test_shipped_planner_configuration_chunked_equals_loop_at_size(ag, O, dev):
     a = torch.cat([planner.sample_action_sequences(act_seq, iter_index=0) for _ in range(2)])
     planner.model_rollout(s0, a)
     ex, need = m.engine(dev).rollout_counts()
-    assert ex == need == int(a[:, 0, 3].to(torch.int32).sum())
+    assert need == int(a[:, 0, 3].to(torch.int32).sum()) and ex <= need    # (ex < need: the contact-free prefix is the base rollout's)
+    with m.engine(dev).options(share_prefix=0):
+        planner.model_rollout(s0, a)
+        assert m.engine(dev).rollout_counts() == (need, need)
     assert 5 <= int(a[:, 0, 3].min()) and int(a[:, 0, 3].max()) <= 14
     W = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     want = O.dynamics(W, 3, cloud, loop["act_seq"].cpu().numpy()[None], {k: v for k, v in task.items()})["state_seqs"]

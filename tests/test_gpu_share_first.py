@@ -56,7 +56,7 @@ def test_shared_first_forward_is_bit_identical(ag, O, dev, material, cloud_fn, B
     outs = {}
     for streams in (1, 4):
         for chunk in (0, 67):
-            with eng.options(streams=streams, device_decode=1 if device_plan else 0):
+            with eng.options(streams=streams, device_decode=1 if device_plan else 0, share_prefix=0):
                 eng.set_chunk(chunk)
                 try:
                     with eng.options(share_first=1):
@@ -149,7 +149,7 @@ def test_device_planned_rollout_stops_enqueuing_at_the_chunk_maximum(ag, O, dev)
     ppm = _ppm(task, "rope")
     eng = m.engine(dev)
     for streams in (1, 4):
-        with eng.options(streams=streams):
+        with eng.options(streams=streams, share_prefix=0):
             torch.cuda.synchronize()
             got = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]
             enq, bound = eng.launch_counts()

@@ -1,0 +1,146 @@
+"""Contact-free prefix (-m gpu).  Without connect_tools_all a tool acts on the object only through the edges it takes part in
+(reference src/dynamics/dataset/graph.py:233-298: radius test, then top-k), and it takes part in none while no object particle is
+inside its radius.  Until then a candidate's object particles evolve exactly like the start state without a tool - bit for bit on
+this engine, where a row's result does not depend on the rest of the batch.  With option share_prefix that base rollout runs
+once per dynamics() call, every candidate is stepped only from its first contact on, and one that never touches takes the base
+state of its last step (reference src/planning/forward_dynamics.py:156-176 steps all of them).  Everything must be IDENTICAL BITS
+to share_prefix = 0: both pushers, both action paths, one and several streams, one and two look-ahead steps, repeats incl. 0."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import _ppm, POS_TOL
+from test_gpu_more import _task, _grid, _rope, _actions, _model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ag():
+    import adaptigraph_amd
+    return adaptigraph_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import adaptigraph_oracle
+    return adaptigraph_oracle
+
+
+LIMITS = dict(action_lower_lim=[-4.5, -2.5, -3.14, 0.0], action_upper_lim=[0.0, 4.5, 3.14, 9.0])
+
+
+def _first_contact(O, W, cloud, a, task):
+    """first forward (1-based) of look-ahead step 0 whose graph holds a tool edge in the ORACLE's rollout, 0 = never"""
+    tr = []
+    O.dynamics(W, 3, cloud, a[None], task, trace=tr)
+    N_o = cloud.shape[0]
+    for f, rec in enumerate(tr[0][:int(a[0, 3])]):
+        if ((rec["recv"] >= N_o) | (rec["send"] >= N_o)).any():
+            return f + 1
+    return 0
+
+
+@pytest.mark.parametrize("material,cloud_fn,B,H,spread", [
+    ("rope", lambda r: _rope(200, r), 500, 1, 2.5),            # the shipped planner's chunk; most pushes never reach the rope
+    ("rope", lambda r: _rope(200, r), 300, 2, 1.2),            # two look-ahead steps: only the first shares
+    ("granular", lambda r: _grid(14, 0.12, 0.02, r), 300, 1, 1.5),   # five-point pusher, top-k 20
+])
+@pytest.mark.parametrize("device_plan", [False, True])
+def test_contact_free_prefix_is_bit_identical(ag, O, dev, material, cloud_fn, B, H, spread, device_plan):
+    rng = np.random.default_rng(401)
+    task = _task(material, max_nR=40000, **(LIMITS if device_plan else {}))
+    W, m = _model(ag, O, material, 401, dev)
+    cloud = cloud_fn(rng)
+    reps = rng.integers(1, 9, (B, H))
+    reps[3, 0] = 0
+    a_np = _actions(cloud, B, H, reps, rng, spread=spread)
+    a_np[3, 0, 3] = 0.5
+    a_np[5, 0, :2] = cloud[100, [0, 2]]                         # starts on the object: contact at the first forward
+    s0, a = torch.from_numpy(cloud).to(dev), torch.from_numpy(a_np).to(dev)
+    ppm = _ppm(task, material)
+    eng = m.engine(dev)
+    outs = {}
+    for streams in (1, 4):
+        for chunk in (0, 67):
+            with eng.options(streams=streams, device_decode=1 if device_plan else 0):
+                eng.set_chunk(chunk)
+                try:
+                    with eng.options(share_prefix=1):
+                        got = ag.dynamics(s0, a, m, dev, ppm)
+                        ex, need = eng.rollout_counts()
+                    with eng.options(share_prefix=0):
+                        ref = ag.dynamics(s0, a, m, dev, ppm)
+                        ex0, need0 = eng.rollout_counts()
+                finally:
+                    eng.set_chunk(0)
+            assert torch.isfinite(got["state_seqs"]).all()
+            assert torch.equal(got["state_seqs"], ref["state_seqs"]) and torch.equal(got["action_seqs"], ref["action_seqs"]), (streams, chunk)
+            assert need == need0 == int(reps.sum()) and ex0 == need0 and ex < need, (ex, need, ex0, need0)
+            outs[(streams, chunk)] = (got["state_seqs"], ex)
+    first = outs[(1, 0)]
+    assert all(torch.equal(first[0], o[0]) and o[1] == first[1] for o in outs.values())
+    print(f"{material} {B} x {H}: {first[1]} candidate-forwards executed (base rollout included) of {int(reps.sum())} the reference steps "
+          f"({int(reps.sum()) / first[1]:.1f}x fewer)")
+    assert float(first[0][3, 0].abs().max()) == 0.0            # repeat 0 at look-ahead step 0: zeros (:32)
+    if device_plan:
+        return
+    # against the oracle: a candidate that touches at once, and the first few others - incl. where each one's first contact is
+    picks = [5, 0, 1, 2, B - 1]
+    want = O.dynamics(W, 3, cloud, a_np[picks], task)["state_seqs"]
+    err = np.abs(first[0][picks].cpu().numpy() - want).reshape(len(picks), -1).max(1)
+    assert (err <= POS_TOL).sum() >= len(picks) - 1, err        # (a free-running rollout may pass a near-tie)
+    assert _first_contact(O, W, cloud, a_np[5], task) == 1
+    contacts = [_first_contact(O, W, cloud, a_np[b], task) for b in range(12)]
+    assert any(c == 0 for c in contacts), contacts              # the batch does hold candidates that never touch
+
+
+def test_prefix_sharing_when_every_or_no_candidate_touches(ag, O, dev):
+    rng = np.random.default_rng(409)
+    task = _task("rope", max_nR=40000)
+    W, m = _model(ag, O, "rope", 409, dev)
+    cloud = _rope(200, rng)
+    B = 128
+    eng = m.engine(dev)
+    ppm = _ppm(task, "rope")
+    s0 = torch.from_numpy(cloud).to(dev)
+    reps = rng.integers(2, 6, (B, 1))
+    for label, a_np in (("all", _actions(cloud, B, 1, reps, rng, spread=0.0)), ("none", _actions(cloud, B, 1, reps, rng, spread=0.0))):
+        if label == "all":
+            a_np[:, 0, :2] = cloud[rng.integers(0, 200, B)][:, [0, 2]]
+        else:
+            a_np[:, 0, 0] += 40.0
+        a = torch.from_numpy(a_np)
+        with eng.options(share_prefix=1):
+            got = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]
+            ex, need = eng.rollout_counts()
+        with eng.options(share_prefix=0):
+            ref = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]
+        assert torch.equal(got, ref), label
+        base = int(reps.max())
+        assert ex == (need + base if label == "all" else base), (label, ex, need, base)
+        if label == "none":                                      # every candidate = the base rollout at its own repeat count
+            by_rep = {int(r): got[i] for i, r in enumerate(reps[:, 0])}
+            assert all(torch.equal(got[i], by_rep[int(r)]) for i, r in enumerate(reps[:, 0]))
+
+
+def test_prefix_sharing_defaults(ag, O, dev):
+    """auto (-1): from 64 candidates and 32768 rows on, never with connect_tools_all (the tool then sends to every particle)"""
+    rng = np.random.default_rng(419)
+    for material, cloud, B, expect in (("rope", _rope(200, rng), 32, False), ("rope", _rope(600, rng), 64, True),
+                                       ("cloth", _grid(24, 0.3, 0.02, rng), 64, False)):
+        task = _task(material, max_nR=60000)
+        W, m = _model(ag, O, material, 419, dev)
+        reps = np.full((B, 1), 3)
+        a_np = _actions(cloud, B, 1, reps, rng, spread=0.0)
+        a_np[:, 0, 0] += 40.0                                    # nobody touches: with sharing only the base rollout runs
+        got = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(a_np), m, dev, _ppm(task, material))
+        ex, need = m.engine(dev).rollout_counts()
+        assert need == 3 * B and (ex == 3 if expect else ex == need), (material, B, ex, need)
+        assert torch.isfinite(got["state_seqs"]).all()
