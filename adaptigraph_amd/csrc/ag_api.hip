@@ -990,6 +990,24 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         c->d_plan_sums = pl_sums; c->plan_sums_n = n_chunks_all * p->H;
         c->fwd_executed = -1; c->fwd_needed = -1;
     }
+    if (prefix && c->opt.share_prefix < 0) {
+        // Automatic mode: is the base rollout worth its latency-bound forwards?  Census of the FIRST forward (its graph needs
+        // the start state only): how many candidates touch at once.  Sharing is kept when at most half of them do and at least
+        // 64 do not - a batch of pushes aimed at the object (every candidate in contact from the first forward on) steps all
+        // of them anyway.  One tiny kernel and one wait, before any other work of the call is enqueued.
+        ContactPlan cp{};
+        cp.base_states = d_state0; cp.R = 1; cp.eef_xz = d_eef_xz; cp.eef_delta = d_eef_delta; cp.repeat = dev_plan ? pl_repeat : c->d_repeat;
+        cp.B = p->B; cp.H = p->H; cp.N_o = p->N_o; cp.M = p->M; cp.thr = p->adj_thresh;
+        cp.grip = p->gripper_offset; cp.grip_on = p->gripper_enable;
+        int* d_cnt = reinterpret_cast<int*>(c->d_share_stats) + 8;          // two ints behind the share counters
+        cp.count = d_cnt;
+        int h_cnt[2] = {0, 0};
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 8, st));
+        HIPCHK(c, launch_contact_plan(cp, st));
+        HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (2 * h_cnt[0] > h_cnt[1] || h_cnt[1] - h_cnt[0] < 64) prefix = false;
+    }
     const bool loop_dev = dev_plan && !prefix;               // the enqueue loop reads its live counts from the device plan's tables
 
     // Shared first forward (Options::share_first).  dynamics() broadcasts ONE start state to all candidates with a constant

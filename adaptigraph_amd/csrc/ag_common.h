@@ -263,6 +263,10 @@ struct ContactPlan {
     int* rep_eff;               // (B,H) out: forwards left per look-ahead step (step 0: repeat - first contact + 1, or 0; others: repeat)
     int* start;                 // (B,) out: base step the candidate starts from (0 when it never touches or touches at once)
     float* state_seqs;          // (B,H,N_o,3): candidates that never touch get S_repeat at look-ahead step 0 here
+    // census mode (count != null; base_states = the start state, base_y = null, R = 1): nothing is planned or written except
+    // count[0] += candidates with a forward to run whose tool touches at the FIRST forward, count[1] += candidates with a forward
+    // to run; the tool height of the start state is formed here (min object y + gripper offset, forward_dynamics.py:40,80-81)
+    int* count; float grip; int grip_on;
 };
 hipError_t launch_contact_plan(const ContactPlan& p, hipStream_t st);
 // cost kernels (ag_cost.hip)

@@ -459,7 +459,31 @@ __device__ __forceinline__ float contact_dis(float xi, float yi, float zi, float
 }
 constexpr int CT = 256;
 __global__ __launch_bounds__(CT) void k_contact_plan(ContactPlan p) {
+    __shared__ float red[CT];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (p.count) {                                           // census of the first forward (see ContactPlan::count)
+        const int rep = p.repeat[(long)b * p.H];
+        if (rep < 1) return;                                 // (uniform over the workgroup)
+        float m = 3.4e38f;
+        for (int i = tid; i < p.N_o; i += CT) m = fminf(m, p.base_states[3 * i + 1]);
+        red[tid] = m;
+        __syncthreads();
+        for (int o = CT / 2; o > 0; o >>= 1) { if (tid < o) red[tid] = fminf(red[tid], red[tid + o]); __syncthreads(); }
+        float ty = red[0];                                   // a minimum: the same bits in any order (k_roll_init: tool_y)
+        if (p.grip_on) ty = ty + p.grip;
+        const float thr2 = __fmul_rn(p.thr, p.thr);
+        int hit = 0;
+        for (int i = tid; i < p.N_o; i += CT) {
+            const float x = p.base_states[3 * i], y = p.base_states[3 * i + 1], z = p.base_states[3 * i + 2];
+            for (int m2 = 0; m2 < p.M; ++m2) {
+                const float* xz = p.eef_xz + ((long)b * p.H * p.M + m2) * 2;
+                hit |= __fsub_rn(contact_dis(x, y, z, xz[0], ty, xz[1]), thr2) < 0.0f ? 1 : 0;
+            }
+        }
+        hit = __syncthreads_or(hit);
+        if (tid == 0) { if (hit) atomicAdd(p.count, 1); atomicAdd(p.count + 1, 1); }
+        return;
+    }
     for (int li = 1 + tid; li < p.H; li += CT) p.rep_eff[(long)b * p.H + li] = p.repeat[(long)b * p.H + li];
     const int rep = min(max(p.repeat[(long)b * p.H], 0), p.R);
     const float thr2 = __fmul_rn(p.thr, p.thr);
