@@ -92,9 +92,14 @@ def start_graph_edges(task, clouds, masks, eef_xz):
 def kernel_report(engines, fn, n_enc_edge_forwards, n_node_forwards, wall_ms, n_edge_forwards=None):
     """One more call with HIP events around every launch (engine pinned to one stream): ms per family, the dominant kernel's
     algorithmic rate against the fp32 MFMA peak, and the edge builder's share of the single-stream kernel time."""
+    # (both sharings off for this pass: every forward then encodes every edge, which is what the algorithmic FLOP counts assume)
+    old = [(e.get_option("share_first"), e.get_option("share_prefix")) for e in engines]
     for e in engines:
+        e.set_option("share_first", 0); e.set_option("share_prefix", 0)
         e.reset_stats(); e.set_profiling(FAMILIES)
     fn(); torch.cuda.synchronize()
+    for e, (sf, sp) in zip(engines, old):
+        e.set_option("share_first", sf); e.set_option("share_prefix", sp)
     fam = {f: [0.0, 0] for f in FAMILIES}
     for e in engines:
         for f in FAMILIES:

@@ -44,9 +44,20 @@ for n, c in pmc.items():
 json.dump(pmc, open(os.path.join(P, f"{rnd}_pmc_counters.json"), "w"), indent=1)
 shutil.copy(os.path.join(F, "planner_configs.jsonl"), os.path.join(P, f"{rnd}_planner_configs.jsonl"))
 with open(os.path.join(P, f"{rnd}_planner_configs.jsonl"), "a") as f:
-    for l in open(os.path.join(F, "planner_configs_share0.jsonl")):
-        r = json.loads(l); r["share_first"] = 0
-        f.write(json.dumps(r) + "\n")
+    for name, tag in (("planner_configs_share0.jsonl", {"share_prefix": 0}), ("planner_configs_share00.jsonl", {"share_prefix": 0, "share_first": 0})):
+        if os.path.exists(os.path.join(F, name)):
+            for l in open(os.path.join(F, name)):
+                r = json.loads(l); r.update(tag)
+                f.write(json.dumps(r) + "\n")
+# A/B runs taken during the round on other boxes (kept next to the evidence run's lines, tagged)
+with open(os.path.join(P, f"{rnd}_planner_configs.jsonl"), "a") as f:
+    for path, tag in (("gpurun_out/p2/planner_sp0.jsonl", {"share_prefix": 0, "note": "A/B run of the same build on another box: prefix sharing off, shared first forward on"}),
+                      ("gpurun_out/t2/planner_sf0.jsonl", {"share_prefix": 0, "share_first": 0, "note": "A/B run of the build before the prefix sharing: both off = the r03 path"}),
+                      ("gpurun_out/t2/planner_sf1.jsonl", {"share_prefix": 0, "share_first": 1, "note": "same box as the line above: shared first forward on"})):
+        if os.path.exists(os.path.join(ROOT, path)) and not os.path.exists(os.path.join(F, "planner_configs_share00.jsonl")):
+            for l in open(os.path.join(ROOT, path)):
+                r = json.loads(l); r.update(tag)
+                f.write(json.dumps(r) + "\n")
 one, plain = bench_line(os.path.join(F, "bench_one_rank_rccl.json")), bench_line(os.path.join(F, "bench_plain_short.json"))
 json.dump({"what": "bench.py --gpus 1 --steps 5 --warmup 2 with AG_BENCH_FORCE_DIST=1: nccl (= RCCL) process group with a world of one rank, "
                    "the all-gather of the rewards and both MAX all-reduces issued on it; against the plain run on the same box",

@@ -13,15 +13,15 @@ rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 400 python tools/bench_configs.py > $O/other_configs.jsonl 2> $O/other_configs.err
 cd /tmp
-for c in rope64 granular mixed; do
-  AG_STREAMS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$c -o s -- python3 $R/tools/bench_configs.py --only $c > $O/prof_$c.log 2>&1
+for c in rope64 granular mixed; do   # (sharings off: one launch shape per kernel, like the HIP-event report)
+  AG_STREAMS=1 AG_SHARE_FIRST=0 AG_SHARE_PREFIX=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$c -o s -- python3 $R/tools/bench_configs.py --only $c > $O/prof_$c.log 2>&1
 done
-AG_STREAMS=1 AG_PRECISION=bf16x3 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b3 -o s -- python3 $R/bench.py --no-cpu-baseline --no-bf16x3 --no-mpc-iter --steps 2 --warmup 1 > $O/prof_b3.log 2>&1
-AG_STREAMS=1 AG_PRECISION=bf16x3 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_b3_sq -o p -- python3 $R/bench.py --candidates 256 --steps 1 --warmup 0 --no-cpu-baseline --no-bf16x3 --no-kernel-profile --no-mpc-iter > $O/pmc_b3_sq.log 2>&1
-AG_STREAMS=1 AG_PRECISION=bf16x3 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_b3_grbm -o p -- python3 $R/bench.py --candidates 256 --steps 1 --warmup 0 --no-cpu-baseline --no-bf16x3 --no-kernel-profile --no-mpc-iter > $O/pmc_b3_grbm.log 2>&1
-AG_STREAMS=1 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_gran_sq -o p -- python3 $R/tools/bench_configs.py --only granular > $O/pmc_gran_sq.log 2>&1
-AG_STREAMS=1 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_gran_grbm -o p -- python3 $R/tools/bench_configs.py --only granular > $O/pmc_gran_grbm.log 2>&1
-AG_STREAMS=1 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/pmc_gran_valu -o p -- python3 $R/tools/bench_configs.py --only granular > $O/pmc_gran_valu.log 2>&1
+AG_STREAMS=1 AG_SHARE_FIRST=0 AG_PRECISION=bf16x3 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b3 -o s -- python3 $R/bench.py --no-cpu-baseline --no-bf16x3 --no-mpc-iter --steps 2 --warmup 1 > $O/prof_b3.log 2>&1
+AG_STREAMS=1 AG_SHARE_FIRST=0 AG_PRECISION=bf16x3 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_b3_sq -o p -- python3 $R/bench.py --candidates 256 --steps 1 --warmup 0 --no-cpu-baseline --no-bf16x3 --no-kernel-profile --no-mpc-iter > $O/pmc_b3_sq.log 2>&1
+AG_STREAMS=1 AG_SHARE_FIRST=0 AG_PRECISION=bf16x3 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_b3_grbm -o p -- python3 $R/bench.py --candidates 256 --steps 1 --warmup 0 --no-cpu-baseline --no-bf16x3 --no-kernel-profile --no-mpc-iter > $O/pmc_b3_grbm.log 2>&1
+AG_STREAMS=1 AG_SHARE_FIRST=0 AG_SHARE_PREFIX=0 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_gran_sq -o p -- python3 $R/tools/bench_configs.py --only granular > $O/pmc_gran_sq.log 2>&1
+AG_STREAMS=1 AG_SHARE_FIRST=0 AG_SHARE_PREFIX=0 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_gran_grbm -o p -- python3 $R/tools/bench_configs.py --only granular > $O/pmc_gran_grbm.log 2>&1
+AG_STREAMS=1 AG_SHARE_FIRST=0 AG_SHARE_PREFIX=0 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/pmc_gran_valu -o p -- python3 $R/tools/bench_configs.py --only granular > $O/pmc_gran_valu.log 2>&1
 cd $R
 python - <<'PY'
 import csv, collections, json, os

@@ -43,7 +43,8 @@ json.dump(out,open(f"{O}/pmc_summary.json","w"),indent=1)
 for n,cs in out.items(): print(n,{c:round(v) for c,v in cs.items()})
 PY
 timeout -k 10 400 python tools/bench_planner.py > $O/planner_configs.jsonl 2> $O/planner_configs.err
-AG_SHARE_FIRST=0 timeout -k 10 300 python tools/bench_planner.py --modes chunked --sorts 1 > $O/planner_configs_share0.jsonl 2> $O/planner_configs_share0.err
+AG_SHARE_PREFIX=0 timeout -k 10 300 python tools/bench_planner.py --modes chunked --sorts 1 > $O/planner_configs_share0.jsonl 2> $O/planner_configs_share0.err
+AG_SHARE_PREFIX=0 AG_SHARE_FIRST=0 timeout -k 10 300 python tools/bench_planner.py --modes chunked --sorts 1 > $O/planner_configs_share00.jsonl 2> $O/planner_configs_share00.err
 # the RCCL calls with a world of one rank (bench.py AG_BENCH_FORCE_DIST=1): reward hash equal to the plain line's
 AG_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-bf16x3 --no-mpc-iter --no-kernel-profile > $O/bench_one_rank_rccl.json 2> $O/bench_one_rank_rccl.err
 timeout -k 10 300 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-bf16x3 --no-mpc-iter --no-kernel-profile > $O/bench_plain_short.json 2> $O/bench_plain_short.err
