@@ -901,8 +901,8 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     int *pl_repeat = nullptr, *pl_cand = nullptr, *pl_live = nullptr, *pl_rows = nullptr, *pl_sums = nullptr;
     float *pl_xz = nullptr, *pl_delta = nullptr;
     c->d_plan_sums = nullptr;
-    // Contact-free prefix (Options::share_prefix; RollArgs::start).  Without connect_tools_all a tool acts on the object only
-    // through the edges it takes part in, and it takes part in none while no object particle is inside its radius.  Until then a
+    // Contact-free prefix (Options::share_prefix; RollArgs::start).  A tool acts on the object only through the edges it takes
+    // part in, and it takes part in none while no object particle is inside its radius.  Until then a
     // candidate's object particles evolve exactly - bit for bit: a row's result does not depend on the rest of its batch - like
     // the start state WITHOUT a tool.  That base rollout is computed once per call (one candidate, tool parked out of reach);
     // k_contact_plan replays every candidate's tool along it and finds the forward of its first contact; a candidate is then
@@ -911,7 +911,9 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     // (plan_utils.py:48-50 with planning/*.yaml:28-29): most of them never reach the object.  Look-ahead step 0 only (later
     // steps start from per-candidate states).  The contact plan decides the launch sizes, so the call waits for it once - the GPU
     // is busy with the base rollout meanwhile.
-    bool prefix = c->opt.share_prefix != 0 && p->y_mode == 0 && !d_obj_mask && !p->connect_tools_all && p->M <= 8;
+    // (connect_tools_all does not change the argument: its tool -> object edges are all-or-nothing on "some object sits inside a
+    // tool particle's radius", graph.py:276-286 - the very contact that is tested; shipped cloth pushes just start on the cloth)
+    bool prefix = c->opt.share_prefix != 0 && p->y_mode == 0 && !d_obj_mask && p->M <= 8;
     if (c->opt.share_prefix < 0 && (p->B < 64 || (long)p->B * N < 32768)) prefix = false;
     int R_base = 0;                                          // steps of the base rollout = the largest repeat of look-ahead step 0
     if (prefix) {
@@ -1101,7 +1103,8 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             ra.write_obj_cls = 1; ra.all_states = b_states; ra.all_y = b_y;
             EdgeArgs ea{};
             ea.pos = w.r.hist + (size_t)(n_his - 1) * N * 3; ea.pos_bstride = (long)n_his * N * 3;
-            ea.mask = w.r.mask; ea.tool = w.r.tool; ea.thr = p->adj_thresh; ea.B = 1; ea.N = N; ea.topk = p->topk; ea.cta = 0;
+            ea.mask = w.r.mask; ea.tool = w.r.tool; ea.thr = p->adj_thresh; ea.B = 1; ea.N = N; ea.topk = p->topk;
+            ea.cta = p->connect_tools_all ? 1 : 0;             // (the parked tool has no object in reach: the rule's flag stays 0)
             ea.edge_cap = edge_cap; ea.slices = slices; ea.ell = w.ell; ea.deg = w.deg; ea.slice_tot = w.slice_tot; ea.cta_flag = w.cta_flag;
             ea.recv = w.recv; ea.send = w.send; ea.row_ptr = w.row_ptr; ea.n_edges = w.n_edges; ea.overflow = d_overflow_flag;
             ea.max_nR = p->max_nR; ea.zero_on_overflow = 1; ea.block_min_rows = c->opt.edge_block_min;

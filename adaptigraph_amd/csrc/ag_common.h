@@ -88,7 +88,7 @@ struct Options {
                               //                     ag_rollout_actions (-1: when the task config bounds the repeat, 0 never, 1 always).
                               //                     The one switch that is NOT bit-neutral: cos/sin of the decode are then the device's,
                               //                     so action_seqs agrees with a host decode to ~1e-7, not bit for bit
-    int share_prefix = -1;    // [AG_SHARE_PREFIX]   contact-free prefix of look-ahead step 0 (connect_tools_all off): candidates whose tool has
+    int share_prefix = -1;    // [AG_SHARE_PREFIX]   contact-free prefix of look-ahead step 0: candidates whose tool has
                               //                     not touched the object yet follow ONE tool-free base rollout (-1: batches of >= 64
                               //                     candidates and >= 32768 rows, 0 never, 1 whenever possible).  Waits once per call
                               //                     for the contact plan (the GPU is busy with the base rollout meanwhile)

@@ -133,12 +133,13 @@ int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
  *                                         candidates, forward_dynamics.py:25): the relation encoder runs once over the
  *                                         object-object edges of the start state's tool-free graph, every candidate reads those
  *                                         C rows; -1 = batches of >= 8 candidates (default), 0 never, 1 whenever possible
- *   "share_prefix"   [AG_SHARE_PREFIX]    contact-free prefix of look-ahead step 0 (y_mode 0, connect_tools_all off): a candidate whose
- *                                         tool has not yet come within adj_thresh of an object particle has no tool edge, so its
+ *   "share_prefix"   [AG_SHARE_PREFIX]    contact-free prefix of look-ahead step 0 (y_mode 0): a candidate whose tool has not yet come
+ *                                         within adj_thresh of an object particle has no tool edge (graph.py:253-286), so its
  *                                         object particles evolve exactly like the start state without a tool.  That base rollout runs
  *                                         once per call; every candidate is stepped only from its first contact on and one that never
  *                                         touches takes the base state of its last step (same bits as stepping it).  -1 = batches of
- *                                         >= 64 candidates and >= 32768 particle rows (default), 0 never, 1 whenever possible.  The call
+ *                                         >= 64 candidates and >= 32768 particle rows of which at most half touch at the first forward
+ *                                         (a census: one more tiny kernel and wait) (default), 0 never, 1 whenever possible.  The call
  *                                         WAITS once for the contact plan (the GPU is running the base rollout meanwhile), so
  *                                         ag_rollout_async / ag_rollout_actions are then not purely asynchronous
  * Unknown names and values outside an option's range return AG_ERR_INVALID (ranges: streams 0..4, chunk 0..2^20, latency -1..1,
