@@ -66,6 +66,12 @@ struct ag_ctx {
     long long fwd_executed = 0, fwd_needed = 0;       // candidate-forwards of the last rollout call (ag_ctx_rollout_counts)
     char* d_plan = nullptr; size_t plan_cap = 0;      // device-planned rollouts (ag_rollout_actions): decoded tool keypoints,
     int* d_plan_sums = nullptr; int plan_sums_n = 0;  // repeats, launch order and per-step live counts; sums pending a read-back
+    // base rollout of the prefix sharing, kept across calls: the reference's planner calls dynamics() 40 times per planner call
+    // with one start state (plan.py:241-247).  Valid for (start state bit-equal, same model / task scalars); [states | heights]
+    float* d_base_cache = nullptr; size_t base_cache_cap = 0; int base_cache_R = -1, base_cache_capR = 0;
+    struct BaseKey { int N_o, M, topk, cta, max_nR, n_his, precision, pstep, grip_on; float thr, grip, phys, clamp; const float* phys_vec;
+                     unsigned long long weights_version; } base_key{};
+    unsigned long long weights_version = 0;
     int* h_rep_pin = nullptr; size_t rep_pin_cap = 0;     // pinned: [forwards left | action_repeat] of a prefix-sharing call (contact plan)
     int* h_plan_max = nullptr; size_t plan_max_cap = 0;   // pinned host copy of RollPlan::maxrep of the call being enqueued
     hipEvent_t ev_plan = nullptr;                       // fires when that copy has landed
@@ -519,6 +525,7 @@ int ag_ctx_destroy(ag_ctx* c) {
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->h_plan_max) (void)hipHostFree(c->h_plan_max);
     if (c->h_rep_pin) (void)hipHostFree(c->h_rep_pin);
+    if (c->d_base_cache) (void)hipFree(c->d_base_cache);
     for (int i = 1; i < ag_ctx::kMaxStreams; ++i) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->aux_stream[i]) (void)hipStreamDestroy(c->aux_stream[i]);
@@ -542,6 +549,7 @@ int ag_ctx_set_precision(ag_ctx* c, int32_t mode) {
     if (mode == c->precision) return AG_OK;
     if (mode == 1 && c->dims.n_his != 4) return fail(c, AG_ERR_UNSUPPORTED, "the bf16x3 chains are built for n_his=4");
     c->precision = mode;
+    ++c->weights_version;
     return c->have_w ? compute_self_rows(c) : AG_OK;
 }
 
@@ -669,6 +677,7 @@ int ag_ctx_load_weights(ag_ctx* c, const float* const* t, int32_t n) {
         HIPCHK(c, hipMemcpy(c->d_wlat, wl.data(), wl.size() * 4, hipMemcpyHostToDevice));
     }
     c->have_w = true;
+    ++c->weights_version;
     return compute_self_rows(c);
 }
 
@@ -915,6 +924,9 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     // tool particle's radius", graph.py:276-286 - the very contact that is tested; shipped cloth pushes just start on the cloth)
     bool prefix = c->opt.share_prefix != 0 && p->y_mode == 0 && !d_obj_mask && p->M <= 8;
     if (c->opt.share_prefix < 0 && (p->B < 64 || (long)p->B * N < 32768)) prefix = false;
+    ag_ctx::BaseKey base_key_now;
+    memset(&base_key_now, 0, sizeof base_key_now);
+    bool census = false, base_cached = false;
     int R_base = 0;                                          // steps of the base rollout = the largest repeat of look-ahead step 0
     if (prefix) {
         if (dev_plan) R_base = R;
@@ -1001,14 +1013,27 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         cp.base_states = d_state0; cp.R = 1; cp.eef_xz = d_eef_xz; cp.eef_delta = d_eef_delta; cp.repeat = dev_plan ? pl_repeat : c->d_repeat;
         cp.B = p->B; cp.H = p->H; cp.N_o = p->N_o; cp.M = p->M; cp.thr = p->adj_thresh;
         cp.grip = p->gripper_offset; cp.grip_on = p->gripper_enable;
-        int* d_cnt = reinterpret_cast<int*>(c->d_share_stats) + 8;          // two ints behind the share counters
+        int* d_cnt = reinterpret_cast<int*>(c->d_share_stats) + 8;          // four ints behind the share counters
         cp.count = d_cnt;
-        int h_cnt[2] = {0, 0};
-        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 8, st));
+        int h_cnt[4] = {0, 0, 0, 0};
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, st));
         HIPCHK(c, launch_contact_plan(cp, st));
-        HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, st));
+        // ... and is the base rollout of an earlier call still good?  (same model and task scalars: compared here; same start
+        // state: compared bit for bit on the device, [3] = words that differ)
+        memset(&base_key_now, 0, sizeof base_key_now);        // (padding bytes too: the keys are compared with memcmp)
+        base_key_now.N_o = p->N_o; base_key_now.M = p->M; base_key_now.topk = p->topk; base_key_now.cta = p->connect_tools_all;
+        base_key_now.max_nR = p->max_nR; base_key_now.n_his = n_his; base_key_now.precision = c->precision;
+        base_key_now.pstep = c->dims.pstep; base_key_now.grip_on = p->gripper_enable; base_key_now.thr = p->adj_thresh;
+        base_key_now.grip = p->gripper_offset; base_key_now.phys = p->physics_param; base_key_now.clamp = c->dims.motion_clamp;
+        base_key_now.phys_vec = d_phys_vec; base_key_now.weights_version = c->weights_version;
+        const bool key_ok = c->base_cache_R >= 1 && !d_phys_vec && memcmp(&base_key_now, &c->base_key, sizeof base_key_now) == 0;
+        if (key_ok) HIPCHK(c, launch_count_diff(d_state0, c->d_base_cache, (long)p->N_o * 3, d_cnt + 3, st));
+        HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         if (2 * h_cnt[0] > h_cnt[1] || h_cnt[1] - h_cnt[0] < 64) prefix = false;
+        R_base = std::min(R_base, std::max(1, h_cnt[2]));     // the batch's own maximum (the device plan only knows the bound)
+        census = true;
+        base_cached = prefix && key_ok && h_cnt[3] == 0 && c->base_cache_R >= R_base;
     }
     const bool loop_dev = dev_plan && !prefix;               // the enqueue loop reads its live counts from the device plan's tables
 
@@ -1077,18 +1102,32 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     const int* d_start = nullptr; const float* d_base_states = nullptr; const float* d_base_y = nullptr;
     if (prefix) {
         Slab& sl = c->slab;
-        float* b_states = sl.take<float>((size_t)(R_base + 1) * p->N_o * 3);
-        float* b_y = sl.take<float>(R_base + 1);
+        float* b_states; float* b_y;
+        if (census && !d_phys_vec) {                         // automatic mode: the base rollout lives in the context, for later calls
+            const size_t need = (size_t)(R_base + 1) * (p->N_o * 3 + 1);
+            if (!base_cached && c->base_cache_cap < need) {
+                if (c->d_base_cache) HIPCHK(c, hipFree(c->d_base_cache));
+                c->d_base_cache = nullptr; c->base_cache_cap = 0; c->base_cache_R = -1;
+                HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_base_cache), need * 4));
+                c->base_cache_cap = need;
+            }
+            if (!base_cached) { c->base_cache_R = -1; c->base_cache_capR = (int)(c->base_cache_cap / (p->N_o * 3 + 1)) - 1; }
+            b_states = c->d_base_cache; b_y = c->d_base_cache + (size_t)(c->base_cache_capR + 1) * p->N_o * 3;
+        } else {
+            b_states = sl.take<float>((size_t)(R_base + 1) * p->N_o * 3);
+            b_y = sl.take<float>(R_base + 1);
+        }
         int* b_rep_eff = sl.take<int>(nrep); int* b_start = sl.take<int>(p->B);
         float* b_eef = sl.take<float>((size_t)5 * p->M);   // parked tool: xz (M,2), delta (M,3)
         int* b_zero = sl.take<int>(1);
         if (sl.used > sl.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
-        std::vector<float> park((size_t)5 * p->M, 0.0f);
-        for (int m = 0; m < 2 * p->M; ++m) park[m] = 1.0e6f;  // out of every particle's reach; delta 0: it stays there
-        HIPCHK(c, hipMemcpyAsync(b_eef, park.data(), park.size() * 4, hipMemcpyHostToDevice, st));   // (pageable: copied before return)
+        const float far = 1.0e6f;                            // out of every particle's reach; delta 0: it stays there
+        int far_bits; memcpy(&far_bits, &far, 4);
+        HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b_eef), far_bits, (size_t)2 * p->M, st));
+        HIPCHK(c, hipMemsetAsync(b_eef + 2 * p->M, 0, (size_t)3 * p->M * 4, st));
         HIPCHK(c, hipMemsetAsync(b_zero, 0, 4, st));
-        HIPCHK(c, hipMemcpyAsync(b_states, d_state0, (size_t)p->N_o * 3 * 4, hipMemcpyDeviceToDevice, st));   // S_0
-        {   // ---- the base rollout: one candidate on workspace 0, R_base forwards, every state recorded
+        if (!base_cached) HIPCHK(c, hipMemcpyAsync(b_states, d_state0, (size_t)p->N_o * 3 * 4, hipMemcpyDeviceToDevice, st));   // S_0
+        if (!base_cached) {   // ---- the base rollout: one candidate on workspace 0, R_base forwards, every state recorded
             Work& w = ws[0];
             GraphBufs g = w.g;
             g.B = 1; g.n_p = p->N_o; g.n_his = n_his; g.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
@@ -1140,14 +1179,21 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         if (!c->ev_plan) HIPCHK(c, hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
         HIPCHK(c, hipMemcpyAsync(c->h_rep_pin, b_rep_eff, nrep * 4, hipMemcpyDeviceToHost, st));
         if (dev_plan) HIPCHK(c, hipMemcpyAsync(c->h_rep_pin + nrep, pl_repeat, nrep * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(c->h_rep_pin + 2 * nrep, d_overflow_flag, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipEventRecord(c->ev_plan, st));
         HIPCHK(c, hipEventSynchronize(c->ev_plan));
+        if (census && !d_phys_vec && !base_cached) {
+            // keep the base rollout for later calls - unless its graphs overflowed max_nR (that call must raise by itself)
+            const bool clean = c->h_rep_pin[2 * nrep] <= p->max_nR;
+            c->base_cache_R = clean ? R_base : -1;
+            c->base_key = base_key_now;
+        }
         if (dev_plan) {
             c->fwd_needed = 0;
             for (size_t i = 0; i < nrep; ++i) c->fwd_needed += std::min(std::max(0, c->h_rep_pin[nrep + i]), R);
             c->d_plan_sums = nullptr;
         }
-        c->fwd_executed = R_base;                             // the base rollout's forwards
+        c->fwd_executed = base_cached ? 0 : R_base;          // the base rollout's forwards (none when an earlier call's is re-used)
         rc = host_plan(c->h_rep_pin);                         // launch order and sizes from the forwards that are LEFT
         if (rc) return rc;
         d_start = b_start; d_base_states = b_states; d_base_y = b_y;

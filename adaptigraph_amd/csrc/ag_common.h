@@ -265,9 +265,12 @@ struct ContactPlan {
     float* state_seqs;          // (B,H,N_o,3): candidates that never touch get S_repeat at look-ahead step 0 here
     // census mode (count != null; base_states = the start state, base_y = null, R = 1): nothing is planned or written except
     // count[0] += candidates with a forward to run whose tool touches at the FIRST forward, count[1] += candidates with a forward
-    // to run; the tool height of the start state is formed here (min object y + gripper offset, forward_dynamics.py:40,80-81)
+    // to run, count[2] = max repeat of look-ahead step 0; the tool height of the start state is formed here (min object y +
+    // gripper offset, forward_dynamics.py:40,80-81)
     int* count; float grip; int grip_on;
 };
+// count += number of 32-bit words in which a and b differ (bitwise)
+hipError_t launch_count_diff(const float* a, const float* b, long n, int* count, hipStream_t st);
 hipError_t launch_contact_plan(const ContactPlan& p, hipStream_t st);
 // cost kernels (ag_cost.hip)
 hipError_t launch_chamfer(const float* x, const float* y, const uint8_t* xm, const uint8_t* ym, int R, int N, int M,

@@ -2,6 +2,7 @@
 // rollout bookkeeping (tool keypoints, history shift, capture).  gfx950 only.  (The edge->node message passing lives in
 // ag_mlp.hip, fused into the propagate chains: gather_agg.)
 #include "ag_common.h"
+#include <algorithm>
 
 namespace ag {
 
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(CT) void k_contact_plan(ContactPlan p) {
             }
         }
         hit = __syncthreads_or(hit);
-        if (tid == 0) { if (hit) atomicAdd(p.count, 1); atomicAdd(p.count + 1, 1); }
+        if (tid == 0) { if (hit) atomicAdd(p.count, 1); atomicAdd(p.count + 1, 1); atomicMax(p.count + 2, rep); }
         return;
     }
     for (int li = 1 + tid; li < p.H; li += CT) p.rep_eff[(long)b * p.H + li] = p.repeat[(long)b * p.H + li];
@@ -515,6 +516,16 @@ __global__ __launch_bounds__(CT) void k_contact_plan(ContactPlan p) {
         float* out = p.state_seqs + (long)b * p.H * p.N_o * 3;
         for (int k = tid; k < p.N_o * 3; k += CT) out[k] = S[k];
     }
+}
+__global__ void k_count_diff(const unsigned* __restrict__ a, const unsigned* __restrict__ b, long n, int* __restrict__ count) {
+    int d = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d += a[i] != b[i] ? 1 : 0;
+    if (d) atomicAdd(count, d);
+}
+hipError_t launch_count_diff(const float* a, const float* b, long n, int* count, hipStream_t st) {
+    hipLaunchKernelGGL(k_count_diff, dim3((unsigned)std::min<long>(64, (n + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const unsigned*>(a), reinterpret_cast<const unsigned*>(b), n, count);
+    return hipGetLastError();
 }
 hipError_t launch_contact_plan(const ContactPlan& p, hipStream_t st) {
     if (p.M > 8) return hipErrorInvalidValue;

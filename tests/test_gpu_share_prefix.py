@@ -146,3 +146,49 @@ def test_prefix_sharing_defaults(ag, O, dev):
         ex, need = m.engine(dev).rollout_counts()
         assert need == 3 * B and (ex == 3 if expect else ex == need), (material, B, ex, need)
         assert torch.isfinite(got["state_seqs"]).all()
+
+
+def test_base_rollout_is_kept_across_calls_with_the_same_start_state(ag, O, dev):
+    """The reference's planner calls dynamics() 40 times per planner call with one start state (plan.py:241-247).  In automatic
+    mode the base rollout of the prefix sharing stays in the context and is re-used while the start state (compared bit for
+    bit on the device), the weights and the task scalars are the same - and recomputed as soon as one of them is not."""
+    rng = np.random.default_rng(431)
+    task = _task("rope", max_nR=40000)
+    W, m = _model(ag, O, "rope", 431, dev)
+    cloud = _rope(600, rng)
+    B = 96
+    eng = m.engine(dev)
+    ppm = _ppm(task, "rope")
+    reps = rng.integers(2, 7, (B, 1))
+    R = int(reps.max())
+    a = torch.from_numpy(_actions(cloud, B, 1, reps, rng, spread=3.0))
+    s0 = torch.from_numpy(cloud).to(dev)
+
+    def run(state, actions=a):
+        out = ag.dynamics(state, actions, m, dev, ppm)["state_seqs"]
+        return out, eng.rollout_counts()[0]
+
+    first, ex1 = run(s0)
+    with eng.options(share_prefix=0):
+        plain, ex0 = run(s0)
+    assert torch.equal(first, plain) and ex1 < ex0
+    again, ex2 = run(s0.clone())                                  # another buffer, the same bits: the kept base rollout serves it
+    assert torch.equal(again, first) and ex2 == ex1 - R, (ex1, ex2, R)
+    a2 = torch.from_numpy(_actions(cloud, B, 1, reps, rng, spread=3.0))
+    other, ex3 = run(s0, a2)                                      # other pushes, same start state: still served
+    with eng.options(share_prefix=0):
+        assert torch.equal(other, run(s0, a2)[0])
+    moved = s0.clone()
+    moved[7, 0] += 1e-6                                           # one ulp-ish change of one coordinate: recomputed
+    got, ex4 = run(moved)
+    with eng.options(share_prefix=0):
+        assert torch.equal(got, run(moved)[0])
+    assert ex4 >= ex2 + R - 2 and not torch.equal(got, first)
+    back, ex5 = run(s0)                                           # and the old one is gone (one slot): recomputed again
+    assert torch.equal(back, first) and ex5 == ex1
+    W2 = O.random_weights(432)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W2.items()})
+    neww, _ = run(s0)                                             # new weights: the kept rollout must not be used
+    with eng.options(share_prefix=0):
+        assert torch.equal(neww, run(s0)[0])
+    assert not torch.equal(neww, first)

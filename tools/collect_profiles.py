@@ -53,7 +53,8 @@ with open(os.path.join(P, f"{rnd}_planner_configs.jsonl"), "a") as f:
 with open(os.path.join(P, f"{rnd}_planner_configs.jsonl"), "a") as f:
     for path, tag in (("gpurun_out/p2/planner_sp0.jsonl", {"share_prefix": 0, "note": "A/B run of the same build on another box: prefix sharing off, shared first forward on"}),
                       ("gpurun_out/t2/planner_sf0.jsonl", {"share_prefix": 0, "share_first": 0, "note": "A/B run of the build before the prefix sharing: both off = the r03 path"}),
-                      ("gpurun_out/t2/planner_sf1.jsonl", {"share_prefix": 0, "share_first": 1, "note": "same box as the line above: shared first forward on"})):
+                      ("gpurun_out/t2/planner_sf1.jsonl", {"share_prefix": 0, "share_first": 1, "note": "same box as the line above: shared first forward on"}),
+                      ("gpurun_out/t7/planner.jsonl", {"note": "final r04 build (base rollout kept across calls), run gpurun_t7.sh"})):
         if os.path.exists(os.path.join(ROOT, path)) and not os.path.exists(os.path.join(F, "planner_configs_share00.jsonl")):
             for l in open(os.path.join(ROOT, path)):
                 r = json.loads(l); r.update(tag)
