@@ -1073,6 +1073,17 @@ def test_rollout_with_the_softbody_model_variant_vs_reference_golden(ag, dev):
     assert np.abs(dv["state_seqs"].cpu().numpy() - g["state_seqs"]).max() <= POS_TOL
     sub = ag.dynamics(s0, a[1:2], m, dev, _ppm(task, "softbody"))["state_seqs"]
     assert torch.equal(sub, out["state_seqs"][1:2])
+    # the contact-free prefix with five history frames: far pushes appended to the golden's, forced sharing, identical bits
+    far = a.clone()
+    far[..., 0] += 30.0
+    both = torch.cat([a, far, far])
+    eng = m.engine(dev)
+    with eng.options(share_prefix=1):
+        shared = ag.dynamics(s0, both, m, dev, _ppm(task, "softbody"))["state_seqs"]
+        ex, need = eng.rollout_counts()
+    with eng.options(share_prefix=0):
+        plain = ag.dynamics(s0, both, m, dev, _ppm(task, "softbody"))["state_seqs"]
+    assert torch.equal(shared, plain) and torch.equal(shared[:len(a)], out["state_seqs"]) and ex < need
     N = g["state0"].shape[0] + 1
     mask = torch.ones((3, N), dtype=torch.bool, device=dev)
     tool = torch.zeros((3, N), dtype=torch.bool, device=dev)

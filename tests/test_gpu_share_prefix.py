@@ -192,3 +192,41 @@ def test_base_rollout_is_kept_across_calls_with_the_same_start_state(ag, O, dev)
     with eng.options(share_prefix=0):
         assert torch.equal(neww, run(s0)[0])
     assert not torch.equal(neww, first)
+
+
+def test_prefix_sharing_in_bf16x3_mode_with_per_particle_physics_and_on_overflow(ag, O, dev):
+    rng = np.random.default_rng(443)
+    task = _task("rope", max_nR=40000)
+    W, m = _model(ag, O, "rope", 443, dev)
+    cloud = _rope(200, rng)
+    B = 80
+    reps = rng.integers(1, 6, (B, 1))
+    a = torch.from_numpy(_actions(cloud, B, 1, reps, rng, spread=2.5))
+    s0 = torch.from_numpy(cloud).to(dev)
+    eng = m.engine(dev)
+    ppm = _ppm(task, "rope")
+
+    def both(ppm_, **kw):
+        with eng.options(share_prefix=1):
+            x = ag.dynamics(s0, a, m, dev, ppm_, **kw)["state_seqs"]
+            ex, need = eng.rollout_counts()
+        with eng.options(share_prefix=0):
+            y = ag.dynamics(s0, a, m, dev, ppm_, **kw)["state_seqs"]
+        assert torch.equal(x, y) and ex < need
+        return x
+
+    fp32 = both(ppm)
+    m.set_precision("bf16x3")
+    try:
+        b3 = both(ppm)
+    finally:
+        m.set_precision("fp32")
+    assert float((b3 - fp32).abs().max()) <= 1e-4 and not torch.equal(b3, fp32)
+    pp = both(ppm, physics_param={"rope": torch.from_numpy(rng.uniform(0.2, 0.8, 200).astype(np.float32))})   # (N_o,) per particle
+    assert not torch.equal(pp, fp32)
+    tight = _ppm(dict(task, max_nR=500), "rope")                  # the base graph alone exceeds it: the reference raises (utils.py:63-65)
+    for sp in (1, 0):
+        with eng.options(share_prefix=sp):
+            with pytest.raises(Exception, match="Exceeds max dims"):
+                ag.dynamics(s0, a, m, dev, tight)
+    assert torch.equal(both(ppm), fp32)                           # the context is still good
