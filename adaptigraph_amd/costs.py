@@ -6,8 +6,11 @@ on (B, H) tensors.  `group`: when the candidate batch is sharded over ranks, the
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
+from .context import default_engine, ptr, current_stream
 from .losses import state_stats, _global_max
 
 
@@ -16,18 +19,19 @@ def running_cost(state, action, state_cur, error_func, penalty_func, bbox, group
     """state (B,H,N,3), action (B,H,4) raw, state_cur (N,3) -> {'reward_seqs': (B,)}"""
     bsz, n_look_forward = state.shape[0], state.shape[1]
     state_flat = state.reshape(bsz * n_look_forward, state.shape[2], state.shape[3])
-    error = error_func(state_flat).reshape(bsz, n_look_forward)                        # :35-36
-    # :37 forms 2.0 / (error.max().item() + 1e-6) in Python double precision and rounds to fp32 only when it scales the
-    # error; the same arithmetic on a float64 device scalar needs no host sync
-    error_weight = (2.0 / (_global_max(error, group).to(torch.float64) + 1e-6)).to(torch.float32)
-    collision_penalty = penalty_func(state, action, state_cur)                         # :39
-    st = state_stats(state_flat).reshape(bsz, n_look_forward, 5)                       # :41-44 in one pass
-    xmin, xmax, zmin, zmax = st[..., 1], st[..., 2], st[..., 3], st[..., 4]
+    dev = state.device
+    error = error_func(state_flat).reshape(bsz, n_look_forward).to(torch.float32).contiguous()      # :35-36
+    collision_penalty = penalty_func(state, action, state_cur).to(torch.float32).contiguous()       # :39
+    assert collision_penalty.shape == (bsz, n_look_forward)
+    st = state_stats(state_flat)                                                       # :41-44 in one pass: (B*H, 5)
+    # :37, :45-53 in ONE launch (csrc/ag_cost.hip: k_reward): error_weight = 2.0 / (error.max() + 1e-6) formed in double
+    # precision and rounded to fp32 only when it scales the error, as the reference's Python float does; the box penalty; the
+    # two means; the reward.  A sharded batch all-reduces the error maximum first and hands it in.
+    emax = None if group is None else _global_max(error, group).reshape(1).to(torch.float32).contiguous()
     bb = torch.as_tensor(bbox).to("cpu", torch.float64)
-    zero = torch.zeros_like(xmin)
-    box_penalty = torch.stack([torch.maximum(xmin - float(bb[0, 0]), zero), torch.maximum(float(bb[0, 1]) - xmax, zero),
-                               torch.maximum(zmin - float(bb[1, 0]), zero), torch.maximum(float(bb[1, 1]) - zmax, zero)],
-                              dim=-1)                                                  # :45-50
-    box_penalty = torch.exp(-box_penalty * 100.0).max(dim=-1).values                   # :51
-    reward = -error_weight * error[:, -1] - 5.0 * collision_penalty.mean(dim=1) - 5.0 * box_penalty.mean(dim=1)   # :53
+    bbox4 = (C.c_double * 4)(float(bb[0, 0]), float(bb[0, 1]), float(bb[1, 0]), float(bb[1, 1]))
+    reward = torch.empty(bsz, device=dev, dtype=torch.float32)
+    eng = default_engine(dev)
+    eng.check(eng.lib.ag_cost_reward(eng.ctx, current_stream(dev), ptr(error), ptr(collision_penalty), ptr(st), ptr(emax), bbox4,
+                                     bsz, n_look_forward, ptr(reward)))
     return {"reward_seqs": reward}

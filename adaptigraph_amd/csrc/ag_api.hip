@@ -1407,6 +1407,28 @@ int ag_cost_penalty(ag_ctx* c, void* stream, const float* d_state_pred, const fl
     return AG_OK;
 }
 
+int ag_cost_reward(ag_ctx* c, void* stream, const float* d_error, const float* d_penalty, const float* d_stats,
+                   const float* d_error_max, const double* h_bbox4, int32_t B, int32_t H, float* d_reward) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_error || !d_penalty || !d_stats || !h_bbox4 || !d_reward || B < 1 || H < 1)
+        return fail(c, AG_ERR_INVALID, "ag_cost_reward: bad arguments B=%d H=%d", B, H);
+    HIPCHK(c, hipSetDevice(c->device));
+    c->prof_stream = static_cast<hipStream_t>(stream);
+    Scoped p(c, FAM_COST);
+    HIPCHK(c, launch_reward(d_error, d_penalty, d_stats, d_error_max, h_bbox4, B, H, d_reward, static_cast<hipStream_t>(stream)));
+    return AG_OK;
+}
+
+int ag_cost_cloth_combine(ag_ctx* c, void* stream, const float* d_raw, const float* d_dmax, int64_t n, float* d_out) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_raw || !d_out || n < 1) return fail(c, AG_ERR_INVALID, "ag_cost_cloth_combine: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->prof_stream = static_cast<hipStream_t>(stream);
+    Scoped p(c, FAM_COST);
+    HIPCHK(c, launch_cloth_combine(d_raw, d_dmax, (long)n, d_out, static_cast<hipStream_t>(stream)));
+    return AG_OK;
+}
+
 int ag_mppi_sample(ag_ctx* c, void* stream, const float* d_act_seq, const float* d_lo, const float* d_hi, const float* d_rnd,
                    const float* d_scale, int32_t S, int32_t H, int32_t mode, float push_length, float* d_out) {
     if (!c) return AG_ERR_INVALID;

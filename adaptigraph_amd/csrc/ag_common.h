@@ -279,6 +279,9 @@ hipError_t launch_state_stats(const float* state, int R, int N, const float* box
 hipError_t launch_penalty(const float* state_pred, const float* action, const float* state_init, int B, int H, int N,
                           int kind, float ratio, float* out, hipStream_t st);
 size_t chamfer_max_points();
+hipError_t launch_reward(const float* error, const float* pen, const float* stats, const float* emax, const double* bbox4, int B,
+                         int H, float* out, hipStream_t st);
+hipError_t launch_cloth_combine(const float* raw, const float* dmax, long n, float* out, hipStream_t st);
 
 // MPPI sampling / update (ag_mppi.hip)
 hipError_t launch_mppi_sample(const float* act_seq, const float* lo, const float* hi, const float* rnd,

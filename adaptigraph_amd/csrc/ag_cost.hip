@@ -199,6 +199,78 @@ __global__ __launch_bounds__(CT) void k_penalty(PenDev a) {
     }
 }
 
+// ---- what is left of running_cost once the particle reductions are done (plan.py:35-53), in ONE launch instead of ~30
+// element-wise torch kernels on (B,H) tensors (a planner call evaluates 80 batches: the launches were 15 % of it):
+//   error_weight = fp32(2 / (double(max error) + 1e-6))                                               plan.py:37
+//   box_penalty[b,h] = max over the four sides of exp(-max(side violation, 0) * 100)                    plan.py:41-51
+//   reward[b] = -error_weight * error[b,-1] - 5 * mean_h penalty[b,h] - 5 * mean_h box_penalty[b,h]    plan.py:53
+// fp32 operations in the reference's order; the mean is sum * fp32(1/H) as torch's mean kernel forms it.  One workgroup:
+// it needs the batch-global error maximum first (given by the caller when the batch is sharded and the maximum all-reduced).
+struct RewardDev {
+    const float* error; const float* pen; const float* stats; const float* emax; float* out;
+    int B, H; float bx0, bx1, bz0, bz1;
+};
+constexpr int RW = 1024;
+__global__ __launch_bounds__(RW) void k_reward(RewardDev a) {
+    __shared__ float red[RW];
+    const int tid = threadIdx.x;
+    float mx;
+    if (a.emax) mx = a.emax[0];
+    else {
+        float m = -3.4e38f;
+        bool nan = false;
+        for (long i = tid; i < (long)a.B * a.H; i += RW) { const float e = a.error[i]; nan |= e != e; m = fmaxf(m, e); }
+        red[tid] = nan ? __builtin_nanf("") : m;
+        __syncthreads();
+        for (int o = RW / 2; o > 0; o >>= 1) {
+            if (tid < o) { const float x = red[tid], y = red[tid + o]; red[tid] = (x != x || y != y) ? __builtin_nanf("") : fmaxf(x, y); }
+            __syncthreads();
+        }
+        mx = red[0];                                         // (torch.max propagates NaN: so does this)
+    }
+    const float ew = (float)(2.0 / ((double)mx + 1e-6));
+    const float inv_h = (float)(1.0 / (double)a.H);
+    for (int b = tid; b < a.B; b += RW) {
+        float ps = 0.f, bs = 0.f;
+        for (int h = 0; h < a.H; ++h) {
+            const float* st = a.stats + ((long)b * a.H + h) * 5;
+            const float v0 = fmaxf(st[1] - a.bx0, 0.f), v1 = fmaxf(a.bx1 - st[2], 0.f);
+            const float v2 = fmaxf(st[3] - a.bz0, 0.f), v3 = fmaxf(a.bz1 - st[4], 0.f);
+            const float e0 = expf(-v0 * 100.0f), e1 = expf(-v1 * 100.0f), e2 = expf(-v2 * 100.0f), e3 = expf(-v3 * 100.0f);
+            bs += fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
+            ps += a.pen[(long)b * a.H + h];
+        }
+        a.out[b] = -ew * a.error[(long)b * a.H + a.H - 1] - 5.0f * (ps * inv_h) - 5.0f * (bs * inv_h);
+    }
+}
+hipError_t launch_reward(const float* error, const float* pen, const float* stats, const float* emax, const double* bbox4, int B,
+                         int H, float* out, hipStream_t st) {
+    RewardDev a{error, pen, stats, emax, out, B, H, (float)bbox4[0], (float)bbox4[1], (float)bbox4[2], (float)bbox4[3]};
+    hipLaunchKernelGGL(k_reward, dim3(1), dim3(RW), 0, st, a);
+    return hipGetLastError();
+}
+// cloth_penalty's tail (losses.py:62-63): 1 - e0 - 0.2 * e1 / max_batch(e1), from the (B,H,2) output of k_penalty
+__global__ __launch_bounds__(RW) void k_cloth_combine(const float* __restrict__ raw, const float* __restrict__ dmax_in, long n,
+                                                      float* __restrict__ out) {
+    __shared__ float red[RW];
+    const int tid = threadIdx.x;
+    float mx;
+    if (dmax_in) mx = dmax_in[0];
+    else {
+        float m = -3.4e38f;
+        for (long i = tid; i < n; i += RW) m = fmaxf(m, raw[2 * i + 1]);
+        red[tid] = m;
+        __syncthreads();
+        for (int o = RW / 2; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+        mx = red[0];
+    }
+    for (long i = tid; i < n; i += RW) out[i] = 1.0f - raw[2 * i] - (raw[2 * i + 1] / mx) * 0.2f;
+}
+hipError_t launch_cloth_combine(const float* raw, const float* dmax, long n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_cloth_combine, dim3(1), dim3(RW), 0, st, raw, dmax, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_chamfer(const float* x, const float* y, const uint8_t* xm, const uint8_t* ym, int R, int N, int M,
                           int By, float* out, hipStream_t st) {
     ChamferDev a{x, y, xm, ym, out, R, N, M, By};

@@ -289,6 +289,20 @@ int ag_cost_penalty(ag_ctx* ctx, void* stream, const float* d_state_pred, const 
                     const float* d_state_init, int32_t B, int32_t H, int32_t N, int32_t kind, float sim_real_ratio,
                     float* d_out);
 
+/* cloth_penalty's tail (losses.py:62-63) on the (B,H,2) output of ag_cost_penalty(kind 1): d_out[i] = 1 - e0 - 0.2 * e1 / max(e1),
+ * n = B*H entries.  d_dmax: NULL = the maximum over this batch is formed here; else a device float holding it (a sharded batch
+ * all-reduces it first).  One launch. */
+int ag_cost_cloth_combine(ag_ctx* ctx, void* stream, const float* d_raw, const float* d_dmax, int64_t n, float* d_out);
+
+/* What is left of running_cost (src/planning/plan.py:35-53) once the particle reductions are done, in one launch:
+ *   error_weight = fp32(2 / (double(max error) + 1e-6)); box penalty from the x / z bounds of ag_cost_state_stats against
+ *   h_bbox4 = {x_lo, x_hi, z_lo, z_hi} (doubles, rounded to fp32 as torch rounds a Python scalar); reward[b] =
+ *   -error_weight * error[b,H-1] - 5 * mean_h penalty[b,h] - 5 * mean_h box_penalty[b,h].
+ * d_error, d_penalty (B,H); d_stats (B*H,5) as ag_cost_state_stats writes it; d_error_max: NULL = batch maximum formed here,
+ * else a device float holding it (sharded batches all-reduce it first); d_reward (B,). */
+int ag_cost_reward(ag_ctx* ctx, void* stream, const float* d_error, const float* d_penalty, const float* d_stats,
+                   const float* d_error_max, const double* h_bbox4, int32_t B, int32_t H, float* d_reward);
+
 /* ---- MPPI sampling / update: SURVEY §8(f) rank 2 (reference src/planning/plan_utils.py:31-101) ---- */
 
 /* sample_action_seq (plan_utils.py:42-77).  d_act_seq (H,4) nominal actions [x, z, theta, length]; d_lo, d_hi (4,)

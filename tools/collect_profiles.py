@@ -59,6 +59,11 @@ with open(os.path.join(P, f"{rnd}_planner_configs.jsonl"), "a") as f:
             for l in open(os.path.join(ROOT, path)):
                 r = json.loads(l); r.update(tag)
                 f.write(json.dumps(r) + "\n")
+if os.path.exists(os.path.join(ROOT, "gpurun_out/t9/phases.jsonl")):
+    with open(os.path.join(P, f"{rnd}_planner_configs.jsonl"), "a") as f:
+        for l in open(os.path.join(ROOT, "gpurun_out/t9/phases.jsonl")):
+            r = json.loads(l); r["note"] = "tools/probe_planner_phases.py, final r04 build with the fused reward kernel: chunked planner call, pipelined and per phase"
+            f.write(json.dumps(r) + "\n")
 one, plain = bench_line(os.path.join(F, "bench_one_rank_rccl.json")), bench_line(os.path.join(F, "bench_plain_short.json"))
 json.dump({"what": "bench.py --gpus 1 --steps 5 --warmup 2 with AG_BENCH_FORCE_DIST=1: nccl (= RCCL) process group with a world of one rank, "
                    "the all-gather of the rewards and both MAX all-reduces issued on it; against the plain run on the same box",
