@@ -241,8 +241,12 @@ int ag_rollout(ag_ctx* ctx, void* stream, const ag_rollout_params* p, const floa
                const float* d_eef_xz, const float* d_eef_delta, const int32_t* h_repeat, const float* d_phys_vec,
                float* d_state_seqs);
 
-/* Same, but never synchronises: enqueue only.  *d_overflow_flag (int32, device, caller-zeroed) receives the max
- * edge count seen if it exceeded max_nR.  Used by bench.py to time the pure device path. */
+/* Same, but does not wait for the rollout: enqueue only.  *d_overflow_flag (int32, device, caller-zeroed) receives the max
+ * edge count seen if it exceeded max_nR.  Used by bench.py to time the pure device path.  One exception: a call that shares the
+ * contact-free prefix (option "share_prefix": y_mode 0, by default batches of >= 64 candidates and >= 32768 rows) waits for the
+ * small plan kernels at its start - once for the census of the first forward (automatic mode), once for the contact plan, the
+ * GPU running the base rollout meanwhile - before it enqueues the candidates' launches; "share_prefix" 0 keeps the call purely
+ * asynchronous. */
 int ag_rollout_async(ag_ctx* ctx, void* stream, const ag_rollout_params* p, const float* d_state0,
                      const uint8_t* d_obj_mask, const float* d_eef_xz, const float* d_eef_delta,
                      const int32_t* h_repeat, const float* d_phys_vec, float* d_state_seqs,
@@ -251,7 +255,7 @@ int ag_rollout_async(ag_ctx* ctx, void* stream, const ag_rollout_params* p, cons
 /* dynamics() for actions that are RESIDENT ON THE GPU (the planner samples them there): decode_action
  * (src/planning/plan_utils.py:11-20), the tool-keypoint layout (forward_dynamics.py:42-75) and the repeat-aware launch plan
  * all run in one device kernel; the host never reads an action, so nothing between the caller's sampling kernel and the
- * first rollout kernel waits for the GPU.  Enqueue only (like ag_rollout_async).
+ * first rollout kernel waits for the GPU.  Enqueue only (like ag_rollout_async, incl. its "share_prefix" exception).
  *   d_action        (B,H,4) raw [x, z, theta, length]
  *   push_length     task_config push_length;  h_tool_offsets (M,) HOST: pusher_points[k][1] * sim_real_ratio (entry 0 unused;
  *                   may be NULL when M == 1)
