@@ -75,6 +75,8 @@ struct ag_ctx {
     int* h_rep_pin = nullptr; size_t rep_pin_cap = 0;     // pinned: [forwards left | action_repeat] of a prefix-sharing call (contact plan)
     int* h_plan_max = nullptr; size_t plan_max_cap = 0;   // pinned host copy of RollPlan::maxrep of the call being enqueued
     hipEvent_t ev_plan = nullptr;                       // fires when that copy has landed
+    hipEvent_t ev_done = nullptr; hipStream_t last_stream = nullptr; bool have_done = false;   // end of the last rollout call: a call on
+                                                        // ANOTHER stream waits for it (the workspace and the plans are per-context)
     long long steps_enqueued = 0, steps_bound = 0;      // model forwards (per chunk) enqueued by the last rollout call / what the bound alone gives
     int* d_overflow = nullptr;
     unsigned long long* d_share_stats = nullptr;      // shared first forward: [0] slots served by the base table, [1] slots encoded per candidate
@@ -523,6 +525,7 @@ int ag_ctx_destroy(ag_ctx* c) {
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->h_plan_max) (void)hipHostFree(c->h_plan_max);
     if (c->h_rep_pin) (void)hipHostFree(c->h_rep_pin);
     if (c->d_base_cache) (void)hipFree(c->d_base_cache);
@@ -852,6 +855,13 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     c->prof_stream = st;
 
     const size_t nrep = (size_t)p->B * p->H;
+    // A caller may be capturing this call into a hipGraph (tools/graph_replay.py): nothing of it may then look at the host side of
+    // an event or wait - no polling of the plan's maxima, no prefix sharing (both only save work; results are the same)
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap_status) == hipSuccess && cap_status == hipStreamCaptureStatusActive;
+    // the previous rollout call of this context may still be running on another stream: its workspace, plan and repeat tables are
+    // this call's too, so this stream waits for it (same stream: stream order already does)
+    if (!capturing && c->have_done && c->last_stream != st) HIPCHK(c, hipStreamWaitEvent(st, c->ev_done, 0));
     HIPCHK(c, hipMemsetAsync(d_state_seqs, 0, (size_t)p->B * p->H * p->N_o * 3 * 4, st));   // forward_dynamics.py:32
 
     const int k = std::min(N, p->topk);
@@ -922,7 +932,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     // is busy with the base rollout meanwhile.
     // (connect_tools_all does not change the argument: its tool -> object edges are all-or-nothing on "some object sits inside a
     // tool particle's radius", graph.py:276-286 - the very contact that is tested; shipped cloth pushes just start on the cloth)
-    bool prefix = c->opt.share_prefix != 0 && p->y_mode == 0 && !d_obj_mask && p->M <= 8;
+    bool prefix = c->opt.share_prefix != 0 && p->y_mode == 0 && !d_obj_mask && p->M <= 8 && !capturing;
     if (c->opt.share_prefix < 0 && (p->B < 64 || (long)p->B * N < 32768)) prefix = false;
     ag_ctx::BaseKey base_key_now;
     memset(&base_key_now, 0, sizeof base_key_now);
@@ -998,8 +1008,10 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             c->plan_max_cap = n_max + 64;
         }
         if (!c->ev_plan) HIPCHK(c, hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
-        HIPCHK(c, hipMemcpyAsync(c->h_plan_max, rp.maxrep, n_max * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipEventRecord(c->ev_plan, st));
+        if (!capturing) {
+            HIPCHK(c, hipMemcpyAsync(c->h_plan_max, rp.maxrep, n_max * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipEventRecord(c->ev_plan, st));
+        }
         d_eef_xz = pl_xz; d_eef_delta = pl_delta;
         c->d_plan_sums = pl_sums; c->plan_sums_n = n_chunks_all * p->H;
         c->fwd_executed = -1; c->fwd_needed = -1;
@@ -1285,7 +1297,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             for (int ai = 1; ai <= max_rep; ++ai) {           // forward_dynamics.py:156
                 if (loop_dev) {
                     // past this chunk's own maximum no slot is live: stop as soon as the plan's maxima are known (no waiting)
-                    if (!plan_landed && ai > 1) {
+                    if (!plan_landed && ai > 1 && !capturing) {
                         if (hipEventQuery(c->ev_plan) == hipSuccess) plan_landed = true;
                         else (void)hipGetLastError();       // "not ready" must not be taken for a failed launch by the next check
                     }
@@ -1327,6 +1339,10 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             rc_join = fail(c, AG_ERR_HIP, "joining stream %d failed: %s", i, hipGetErrorString(e));
     }
     c->prof_stream = st;
+    if (!capturing) {                                        // (a captured event could not be waited for outside its graph)
+        if (!c->ev_done && hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) c->ev_done = nullptr;
+        if (c->ev_done && hipEventRecord(c->ev_done, st) == hipSuccess) { c->have_done = true; c->last_stream = st; }
+    }
     return rc_loop ? rc_loop : rc_join;
 }
 }  // namespace

@@ -19,9 +19,12 @@
  *     comment says so.
  *   - The caller owns every input/output buffer.  The library owns only its
  *     ctx workspace (grown monotonically, freed by ag_ctx_destroy).
- *   - One ctx per (process, device); a ctx is not re-entrant.  All rollout calls of a ctx (ag_rollout, ag_rollout_async,
- *     ag_rollout_actions) must be issued on ONE stream, or serialised by the caller: the launch plan, the repeat table and
- *     the workspace are per-ctx state that the kernels of a call read until that call's work has drained.
+ *   - One ctx per (process, device); a ctx is not re-entrant (one host thread at a time).  The launch plan, the repeat table
+ *     and the workspace are per-ctx state that the kernels of a call read until that call's work has drained: a rollout call
+ *     (ag_rollout, ag_rollout_async, ag_rollout_actions) issued on ANOTHER stream than the previous one first makes its stream wait
+ *     for the previous call's end (an event; calls on one stream are ordered by the stream).  Early returns before any
+ *     work was enqueued (argument errors) record nothing.  A call that is being captured into a hipGraph neither waits nor records:
+ *     the caller serialises around a capture.
  *   - No float atomics anywhere: results are bit-reproducible and independent
  *     of how candidates are chunked or sharded across GPUs.
  */

@@ -230,3 +230,60 @@ def test_prefix_sharing_in_bf16x3_mode_with_per_particle_physics_and_on_overflow
             with pytest.raises(Exception, match="Exceeds max dims"):
                 ag.dynamics(s0, a, m, dev, tight)
     assert torch.equal(both(ppm), fp32)                           # the context is still good
+
+
+def test_a_device_planned_call_can_be_captured_in_a_hip_graph(ag, O, dev):
+    """A caller may capture an asynchronous dynamics() call (GPU-resident actions, _sync=False) into a hipGraph: the call must then
+    neither wait nor look at the host side of an event - no polling of the plan's maxima, no prefix sharing - and a replay must
+    reproduce the eager result bit for bit (tools/graph_replay.py measures the latency of exactly this)."""
+    rng = np.random.default_rng(457)
+    task = _task("rope", max_nR=40000, action_lower_lim=[-4.5, -2.5, -3.14, 0.0], action_upper_lim=[0.0, 4.5, 3.14, 6.0])
+    W, m = _model(ag, O, "rope", 457, dev)
+    cloud = _rope(150, rng)
+    s0 = torch.from_numpy(cloud).to(dev)
+    ppm = _ppm(task, "rope")
+    flag = torch.zeros(4, dtype=torch.int32, device=dev)
+    for B in (1, 96):                                            # latency-mode single graph; a batch the prefix sharing would take eagerly
+        a = torch.from_numpy(_actions(cloud, B, 1, rng.integers(1, 6, (B, 1)), rng, spread=2.0)).to(dev)
+        call = lambda: ag.dynamics(s0, a, m, dev, ppm, _sync=False, _overflow_flag=flag)["state_seqs"]
+        with m.engine(dev).options(share_prefix=1 if B > 1 else -1):
+            ref = call().clone()
+            torch.cuda.synchronize()                             # (one stream per context at a time: include/adaptigraph_amd.h)
+            side = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    call()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                got = call()
+            got.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), B
+            assert torch.equal(call(), ref)                      # and the context is as good as before
+            torch.cuda.synchronize()
+
+
+def test_rollout_calls_on_different_streams_of_one_context_are_serialised(ag, O, dev):
+    """The workspace and the plans are per-context: an asynchronous call on another stream than the previous one waits for it
+    (include/adaptigraph_amd.h).  Back-to-back asynchronous calls alternating between two streams, no synchronisation in between:
+    every result equals the synchronous one."""
+    rng = np.random.default_rng(461)
+    task = _task("rope", max_nR=40000, action_lower_lim=[-4.5, -2.5, -3.14, 0.0], action_upper_lim=[0.0, 4.5, 3.14, 6.0])
+    W, m = _model(ag, O, "rope", 461, dev)
+    cloud = _rope(150, rng)
+    s0 = torch.from_numpy(cloud).to(dev)
+    ppm = _ppm(task, "rope")
+    flag = torch.zeros(4, dtype=torch.int32, device=dev)
+    acts = [torch.from_numpy(_actions(cloud, 96, 1, rng.integers(1, 6, (96, 1)), rng, spread=2.0)).to(dev) for _ in range(6)]
+    want = [ag.dynamics(s0, a, m, dev, ppm)["state_seqs"].clone() for a in acts]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    got = []
+    for i, a in enumerate(acts):
+        with torch.cuda.stream(streams[i % 2]):
+            got.append(ag.dynamics(s0, a, m, dev, ppm, _sync=False, _overflow_flag=flag)["state_seqs"])
+    torch.cuda.synchronize()
+    for i in range(len(acts)):
+        assert torch.equal(got[i], want[i]), i
