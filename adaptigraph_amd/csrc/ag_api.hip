@@ -1018,9 +1018,9 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     }
     if (prefix && c->opt.share_prefix < 0) {
         // Automatic mode: is the base rollout worth its latency-bound forwards?  Census of the FIRST forward (its graph needs
-        // the start state only): how many candidates touch at once.  Sharing is kept when at most half of them do and at least
-        // 64 do not - a batch of pushes aimed at the object (every candidate in contact from the first forward on) steps all
-        // of them anyway.  One tiny kernel and one wait, before any other work of the call is enqueued.
+        // the start state only): how many candidates touch at once.  Sharing is kept when enough of them do not - a batch of
+        // pushes aimed at the object (every candidate in contact from the first forward on) steps all of them anyway.  One
+        // tiny kernel and one wait, before any other work of the call is enqueued.
         ContactPlan cp{};
         cp.base_states = d_state0; cp.R = 1; cp.eef_xz = d_eef_xz; cp.eef_delta = d_eef_delta; cp.repeat = dev_plan ? pl_repeat : c->d_repeat;
         cp.B = p->B; cp.H = p->H; cp.N_o = p->N_o; cp.M = p->M; cp.thr = p->adj_thresh;
@@ -1042,8 +1042,10 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         if (key_ok) HIPCHK(c, launch_count_diff(d_state0, c->d_base_cache, (long)p->N_o * 3, d_cnt + 3, st));
         HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
-        if (2 * h_cnt[0] > h_cnt[1] || h_cnt[1] - h_cnt[0] < 64) prefix = false;
         R_base = std::min(R_base, std::max(1, h_cnt[2]));     // the batch's own maximum (the device plan only knows the bound)
+        // worth it when enough candidates are still free at the first forward to pay for the base rollout's latency-bound
+        // forwards (each costs about as much as eight candidate-forwards of a full launch)
+        if (h_cnt[1] - h_cnt[0] < std::max(64, 8 * R_base)) prefix = false;
         census = true;
         base_cached = prefix && key_ok && h_cnt[3] == 0 && c->base_cache_R >= R_base;
     }
@@ -1059,8 +1061,8 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     // there (k_ell_index: send_pk); per candidate only the edges with a tool at either end are encoded.  Bit-identical: a
     // row's chain does not depend on the lane / workgroup / launch that computes it.
     const int kb = std::min(p->N_o, p->topk);
-    bool share = c->opt.share_first != 0 && p->y_mode == 0 && !d_obj_mask && ell_full && p->topk < p->N_o && k <= 255 &&
-                 !prefix;   // (with the prefix sharing a candidate's first own forward is no longer the start state's)
+    // (with the prefix sharing only the candidates that touch at once start from the start state: EdgeArgs::share_start)
+    bool share = c->opt.share_first != 0 && p->y_mode == 0 && !d_obj_mask && ell_full && p->topk < p->N_o && k <= 255;
     if (c->opt.share_first < 0 && p->B < 8) share = false;   // a handful of candidates: the base build costs more than it saves
     {   // launches small enough for the latency-mode propagate chains (ag_lat.hip) keep their own C rows
         GraphBufs gt{};
@@ -1318,6 +1320,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
                 if (share_step) {
                     ea.base_send = base_send; ea.base_deg = base_deg; ea.base_stride = kb; ea.share_No = p->N_o;
                     ea.share_stats = c->d_share_stats; g.C_share = C_share; g.share_kb = kb;
+                    ea.share_start = d_start; ea.share_cand = ra.cand; ea.share_b0 = b0;
                 }
                 HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));
                 if (g.ns_edge && !ell_full) { Scoped s(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, n_live, N, edge_cap, w.ns_edge, w.n_ns, ea.live, cs)); }

@@ -134,6 +134,9 @@ struct EdgeArgs {
     // the base table, += slots this candidate encodes itself.
     int* send_pk; const int* base_send; const int* base_deg; int base_stride; int share_No;
     unsigned long long* share_stats;
+    // with the contact-free prefix active only the candidates that start from the start state itself (start == 0) are at "the
+    // first forward": share_start (per candidate, or null = all), share_cand (slot -> candidate, or null = share_b0 + slot)
+    const int* share_start; const int* share_cand; int share_b0;
 };
 hipError_t launch_edge_build(const EdgeArgs& a, hipStream_t st, void (*mark)(void*, int, int), void* mark_ctx);
 // list of non-self-loop edges per candidate (self-loop dedupe, see GraphBufs)

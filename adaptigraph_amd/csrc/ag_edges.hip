@@ -56,6 +56,7 @@ struct EdgeDev {
     const int* live;                     // see EdgeArgs
     int* send_pk; const int* base_send; const int* base_deg; int base_stride, share_No;   // see EdgeArgs (first forward)
     unsigned long long* share_stats;
+    const int* share_start; const int* share_cand; int share_b0;
 };
 
 __device__ __forceinline__ float dist_exact(float xi, float yi, float zi, float xj, float yj, float zj) {
@@ -694,6 +695,8 @@ __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
     // positions every object sender a candidate keeps IS in the base row - a tool can only push senders out of a row's top-k -
     // but nothing relies on it: a sender that is not found is simply encoded by the candidate itself.)
     int* pk = a.send_pk ? a.send_pk + (long)b * a.edge_cap : nullptr;
+    // (prefix sharing: a slot that starts from a later base state is not at the start state's forward - it shares nothing)
+    const bool eligible = !a.share_start || a.share_start[a.share_cand ? a.share_cand[b] : a.share_b0 + b] == 0;
     const int per = (a.N + EW - 1) / EW;
     const int i0 = min(a.N, tid * per), i1 = min(a.N, i0 + per);
     int mine = 0, shared = 0;
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
             int own = j != i ? 1 : 0;
             if (pk) {
                 int v = j;
-                if (own && j < a.share_No)
+                if (own && eligible && j < a.share_No)
                     for (int u = 0; u < bd; ++u)
                         if (brow[u] == j) { v = j | ((u + 1) << 12); own = 0; ++shared; break; }
                 pk[e] = v;
@@ -765,6 +768,7 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     a.max_nR = h.max_nR; a.zero_on_overflow = h.zero_on_overflow; a.live = h.live;
     a.send_pk = a.ell_full ? h.send_pk : nullptr; a.base_send = h.base_send; a.base_deg = h.base_deg; a.base_stride = h.base_stride;
     a.share_No = h.share_No; a.share_stats = h.share_stats;
+    a.share_start = h.share_start; a.share_cand = h.share_cand; a.share_b0 = h.share_b0;
     a.block_min_rows = h.block_min_rows >= 0 ? h.block_min_rows : BLOCK_MIN_ROWS;   // A/B switch (Options::edge_block_min); results identical
     const size_t lds = edge_lds_bytes(h.N);
     // the > 64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: track it per device ordinal
