@@ -49,21 +49,6 @@ with open(os.path.join(P, f"{rnd}_planner_configs.jsonl"), "a") as f:
             for l in open(os.path.join(F, name)):
                 r = json.loads(l); r.update(tag)
                 f.write(json.dumps(r) + "\n")
-# A/B runs taken during the round on other boxes (kept next to the evidence run's lines, tagged)
-with open(os.path.join(P, f"{rnd}_planner_configs.jsonl"), "a") as f:
-    for path, tag in (("gpurun_out/p2/planner_sp0.jsonl", {"share_prefix": 0, "note": "A/B run of the same build on another box: prefix sharing off, shared first forward on"}),
-                      ("gpurun_out/t2/planner_sf0.jsonl", {"share_prefix": 0, "share_first": 0, "note": "A/B run of the build before the prefix sharing: both off = the r03 path"}),
-                      ("gpurun_out/t2/planner_sf1.jsonl", {"share_prefix": 0, "share_first": 1, "note": "same box as the line above: shared first forward on"}),
-                      ("gpurun_out/t7/planner.jsonl", {"note": "final r04 build (base rollout kept across calls), run gpurun_t7.sh"})):
-        if os.path.exists(os.path.join(ROOT, path)) and not os.path.exists(os.path.join(F, "planner_configs_share00.jsonl")):
-            for l in open(os.path.join(ROOT, path)):
-                r = json.loads(l); r.update(tag)
-                f.write(json.dumps(r) + "\n")
-if os.path.exists(os.path.join(ROOT, "gpurun_out/t9/phases.jsonl")):
-    with open(os.path.join(P, f"{rnd}_planner_configs.jsonl"), "a") as f:
-        for l in open(os.path.join(ROOT, "gpurun_out/t9/phases.jsonl")):
-            r = json.loads(l); r["note"] = "tools/probe_planner_phases.py, final r04 build with the fused reward kernel: chunked planner call, pipelined and per phase"
-            f.write(json.dumps(r) + "\n")
 one, plain = bench_line(os.path.join(F, "bench_one_rank_rccl.json")), bench_line(os.path.join(F, "bench_plain_short.json"))
 json.dump({"what": "bench.py --gpus 1 --steps 5 --warmup 2 with AG_BENCH_FORCE_DIST=1: nccl (= RCCL) process group with a world of one rank, "
                    "the all-gather of the rewards and both MAX all-reduces issued on it; against the plain run on the same box",
