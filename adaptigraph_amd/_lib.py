@@ -29,10 +29,11 @@ EXPORTS = ["ag_abi_version", "ag_ctx_create", "ag_ctx_destroy", "ag_last_error",
            "ag_ctx_set_profiling", "ag_ctx_kernel_stats", "ag_ctx_reset_stats",
            "ag_cost_chamfer", "ag_cost_state_stats", "ag_cost_penalty", "ag_ctx_set_precision", "ag_build_edges_single",
            "ag_edges_apply_tool_rule", "ag_mppi_sample", "ag_mppi_update", "ag_mppi_clip",
-           "ag_ctx_set_option", "ag_ctx_get_option", "ag_ctx_rollout_counts", "ag_rollout_actions", "ag_ctx_share_counts", "ag_ctx_launch_counts", "ag_cost_reward", "ag_cost_cloth_combine"]
+           "ag_ctx_set_option", "ag_ctx_get_option", "ag_ctx_rollout_counts", "ag_rollout_actions", "ag_ctx_share_counts", "ag_ctx_launch_counts", "ag_cost_reward", "ag_cost_cloth_combine",
+           "ag_ctx_alloc_counts"]
 
 OPTIONS = ["streams", "chunk", "latency", "ragged", "ell_graph", "self_dedupe", "repeat_sort", "edge_wgs", "edge_block_min",
-           "enc_persist", "stagger_us", "device_decode", "zigzag", "share_first", "share_prefix"]
+           "enc_persist", "stagger_us", "device_decode", "zigzag", "share_first", "share_prefix", "stream_min_rows", "pipeline_fork"]
 
 
 class AgDims(C.Structure):
@@ -75,6 +76,7 @@ def load():
     lib.ag_ctx_rollout_counts.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.ag_ctx_share_counts.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.ag_ctx_launch_counts.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.ag_ctx_alloc_counts.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.ag_build_edges.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp, i32, i32, i32, vp, vp, vp, vp]
     lib.ag_build_edges_single.argtypes = [vp, vp, vp, vp, vp, i32, f32, f32, i32, i32, i32, vp, vp, vp, vp]
     lib.ag_edges_apply_tool_rule.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, C.c_double, i32, vp, vp, vp, vp]

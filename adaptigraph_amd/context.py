@@ -131,6 +131,12 @@ class Engine:
         self.check(self.lib.ag_ctx_launch_counts(self._ctx, out))
         return int(out[0]), int(out[1])
 
+    def alloc_counts(self):
+        """device / pinned allocations and frees, event and stream creations this context has made so far (ag_ctx_alloc_counts)."""
+        out = (C.c_int64 * 1)()
+        self.check(self.lib.ag_ctx_alloc_counts(self._ctx, out))
+        return int(out[0])
+
     def share_counts(self):
         """Shared first forward of the last rollout call (ag_ctx_share_counts): (edges of the once-per-call base encode,
         edge slots served by the shared table, edge slots the candidates encoded themselves at that forward)."""

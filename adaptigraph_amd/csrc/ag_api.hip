@@ -48,6 +48,38 @@ struct ProfEvent { int fam; hipEvent_t e0, e1; };
 
 }  // namespace
 
+// what a kept base rollout of the prefix sharing (and a census verdict) is valid for; compared with memcmp, so always memset +
+// field-wise filled + memcpy'd
+struct BaseKey { int N_o, M, topk, cta, max_nR, n_his, precision, pstep, grip_on; float thr, grip, phys, clamp; const float* phys_vec;
+                 unsigned long long weights_version; };
+
+// Everything a call writes while it is in flight: workspace, launch plans, pinned read-back buffers, the events and streams of
+// its fork / join.  A context keeps up to kMaxSlots of them, one per CALLER STREAM: calls issued on different streams then run
+// side by side on the GPU (the planner's chunk loop, plan.py:241-247, is 40 independent calls on one start state;
+// adaptigraph_amd/planner.py deals them to a few streams), calls on one stream stay ordered by the stream.  A stream that finds no
+// free slot takes over the least recently used one after making itself wait for that slot's last call (an event recorded at the
+// end of every call).  Created on first use, kept until ag_ctx_destroy: a call of a shape the slot has seen allocates nothing.
+struct CallSlot {
+    hipStream_t stream = nullptr; bool bound = false; unsigned long long tick = 0;
+    Slab slab;
+    int* d_repeat = nullptr; size_t repeat_cap = 0;   // device: [repeat (B*H) | launch order (H*B)]
+    std::vector<int> h_repeat;   // slot-owned copy so the caller's array may die right after the call; same layout
+    char* d_plan = nullptr; size_t plan_cap = 0;      // device-planned rollouts (ag_rollout_actions): decoded tool keypoints,
+                                                      // repeats, launch order and per-step live counts
+    int* h_rep_pin = nullptr; size_t rep_pin_cap = 0;     // pinned: [forwards left | action_repeat | flag, census x4] of a prefix-sharing call
+    int* h_plan_max = nullptr; size_t plan_max_cap = 0;   // pinned host copy of RollPlan::maxrep of the call being enqueued
+    int* h_census = nullptr;                            // pinned (8 ints): result of a census nobody waited for (see Decision)
+    hipEvent_t ev_plan = nullptr;                       // fires when a read-back of this call has landed
+    hipEvent_t ev_census = nullptr; bool census_pending = false;   // a census went out on this slot's stream that nobody waited for
+    BaseKey census_key{}; int census_B = 0, census_H = 0, census_R = 0;
+    hipEvent_t ev_done = nullptr; bool have_done = false;   // end of the slot's last call
+    int* d_words = nullptr;      // 64 ints: [0] overflow word of the synchronous entry points, [8..11] census counters
+    unsigned long long* d_share_stats = nullptr;      // shared first forward: [0] slots served by the base table, [1] slots encoded per candidate
+    static constexpr int kMaxStreams = 4;
+    hipStream_t aux_stream[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused: the caller's stream
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
+};
+
 struct ag_ctx {
     int device = 0;
     ag_dims dims{};
@@ -57,36 +89,33 @@ struct ag_ctx {
     float* d_wlat = nullptr;     // weight image of the latency-mode chains (ag_lat.hip), n_his = 4 models only
     int precision = 0;           // 0: exact fp32 MFMA (default), 1: bf16x3 split on the bf16 matrix pipe
     bool have_w = false;
-    Slab slab;
     int chunk = 0;
     Options opt;                 // per-context switches: environment defaults read once at create, ag_ctx_set_option afterwards
     void* diag = nullptr;        // diagnostic build only: probe state of this context (ag_diag.hip)
-    int* d_repeat = nullptr; size_t repeat_cap = 0;   // device: [repeat (B*H) | launch order (H*B)]
-    std::vector<int> h_repeat;   // ctx-owned copy so the caller's array may die right after the call; same layout
+    static constexpr int kMaxSlots = 4;
+    static constexpr int kMaxStreams = CallSlot::kMaxStreams;
+    CallSlot slots[kMaxSlots];
+    unsigned long long slot_tick = 0;
+    int last_slot = 0;           // slot of the last rollout call (the diagnostics below refer to it)
+    long long n_allocs = 0;      // hipMalloc / hipHostMalloc / hipFree / hipHostFree / event and stream creations so far (ag_ctx_alloc_counts)
     long long fwd_executed = 0, fwd_needed = 0;       // candidate-forwards of the last rollout call (ag_ctx_rollout_counts)
-    char* d_plan = nullptr; size_t plan_cap = 0;      // device-planned rollouts (ag_rollout_actions): decoded tool keypoints,
-    int* d_plan_sums = nullptr; int plan_sums_n = 0;  // repeats, launch order and per-step live counts; sums pending a read-back
+    int* d_plan_sums = nullptr; int plan_sums_n = 0;  // device-planned call: sums pending a read-back
     // base rollout of the prefix sharing, kept across calls: the reference's planner calls dynamics() 40 times per planner call
-    // with one start state (plan.py:241-247).  Valid for (start state bit-equal, same model / task scalars); [states | heights]
+    // with one start state (plan.py:241-247).  Valid for (start state bit-equal, same model / task scalars); [states | heights].
+    // Shared by all slots: host-side validity (base_cache_R) is set only after the producing call has waited for its contact plan,
+    // i.e. with the contents complete; a call that overwrites it first makes its stream wait for every other slot's last call.
     float* d_base_cache = nullptr; size_t base_cache_cap = 0; int base_cache_R = -1, base_cache_capR = 0;
-    struct BaseKey { int N_o, M, topk, cta, max_nR, n_his, precision, pstep, grip_on; float thr, grip, phys, clamp; const float* phys_vec;
-                     unsigned long long weights_version; } base_key{};
+    BaseKey base_key{};
+    // the automatic mode's last census verdict "not worth a base rollout" (bench-like batches: every push starts on the object),
+    // for batches of the same key and shape: such a call skips the blocking census, enqueues one that nobody waits for, and the
+    // verdict is revisited when that one has landed (see rollout_impl).  A stale verdict costs time, never a result.
+    struct Decision { bool decline = false; BaseKey key{}; int B = 0, H = 0; } decision;
     unsigned long long weights_version = 0;
-    int* h_rep_pin = nullptr; size_t rep_pin_cap = 0;     // pinned: [forwards left | action_repeat] of a prefix-sharing call (contact plan)
-    int* h_plan_max = nullptr; size_t plan_max_cap = 0;   // pinned host copy of RollPlan::maxrep of the call being enqueued
-    hipEvent_t ev_plan = nullptr;                       // fires when that copy has landed
-    hipEvent_t ev_done = nullptr; hipStream_t last_stream = nullptr; bool have_done = false;   // end of the last rollout call: a call on
-                                                        // ANOTHER stream waits for it (the workspace and the plans are per-context)
     long long steps_enqueued = 0, steps_bound = 0;      // model forwards (per chunk) enqueued by the last rollout call / what the bound alone gives
-    int* d_overflow = nullptr;
-    unsigned long long* d_share_stats = nullptr;      // shared first forward: [0] slots served by the base table, [1] slots encoded per candidate
     const int* d_share_nns = nullptr;                 // edges the base encode ran over (workspace of the last rollout call), or null
     float* d_cself = nullptr;    // (256, NFP): rows 0/1 = C of an object / tool self-loop edge (see GraphBufs)
-    // second in-library stream: alternate chunks run on it so that the HBM-bound kernels of one chunk overlap the
+    // in-library streams of a call: alternate chunks run on them so that the HBM-bound kernels of one chunk overlap the
     // MFMA-bound chains of the other (fork/join with events around every rollout call)
-    static constexpr int kMaxStreams = 4;
-    hipStream_t aux_stream[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused: the caller's stream
-    hipEvent_t ev_fork = nullptr, ev_join[kMaxStreams] = {nullptr, nullptr, nullptr, nullptr};
     int n_streams = 2;
     // profiling
     unsigned prof_mask = 0;
@@ -116,6 +145,8 @@ const OptName kOptions[] = {
     {"zigzag", "AG_ZIGZAG", &Options::zigzag, false, 0, 1},
     {"share_first", "AG_SHARE_FIRST", &Options::share_first, false, -1, 1},
     {"share_prefix", "AG_SHARE_PREFIX", &Options::share_prefix, false, -1, 1},
+    {"stream_min_rows", "AG_STREAM_MIN_ROWS", &Options::stream_min_rows, false, 0, 0x7fffffff},
+    {"pipeline_fork", "AG_PIPELINE_FORK", &Options::pipeline_fork, false, 0, 1},
 };
 void options_from_env(Options& o) {   // values from the environment are clamped into the option's range
     for (const OptName& n : kOptions)
@@ -136,6 +167,72 @@ int fail(ag_ctx* c, int code, const char* fmt, ...) {
         hipError_t _e = (expr);                                                                           \
         if (_e != hipSuccess) return fail(c, AG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
+
+// every allocation / creation the library makes is counted (ag_ctx_alloc_counts): a steady-state call makes none
+hipError_t dev_alloc(ag_ctx* c, void** p, size_t bytes) { ++c->n_allocs; return hipMalloc(p, bytes); }
+hipError_t dev_free(ag_ctx* c, void* p) { ++c->n_allocs; return hipFree(p); }
+hipError_t pin_alloc(ag_ctx* c, void** p, size_t bytes) { ++c->n_allocs; return hipHostMalloc(p, bytes, hipHostMallocDefault); }
+hipError_t pin_free(ag_ctx* c, void* p) { ++c->n_allocs; return hipHostFree(p); }
+hipError_t event_new(ag_ctx* c, hipEvent_t* e) { ++c->n_allocs; return hipEventCreateWithFlags(e, hipEventDisableTiming); }
+hipError_t stream_new(ag_ctx* c, hipStream_t* s) { ++c->n_allocs; return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+
+// The slot of caller stream `st` (see CallSlot).  capturing: the call is being recorded into a hipGraph - it may neither wait for
+// nor record an event that lives outside the graph.
+int slot_acquire(ag_ctx* c, hipStream_t st, bool capturing, CallSlot** out) {
+    CallSlot* s = nullptr;
+    for (CallSlot& k : c->slots) if (k.bound && k.stream == st) { s = &k; break; }
+    if (!s) for (CallSlot& k : c->slots) if (!k.bound) { s = &k; break; }
+    if (!s) {   // every slot belongs to another stream: take the least recently used one, after its last call
+        s = &c->slots[0];
+        for (CallSlot& k : c->slots) if (k.tick < s->tick) s = &k;
+        if (!capturing && s->have_done) HIPCHK(c, hipStreamWaitEvent(st, s->ev_done, 0));
+        s->census_pending = false;
+    }
+    if (!s->ev_done) {   // first use: everything whose size does not depend on the call
+        HIPCHK(c, event_new(c, &s->ev_done));
+        HIPCHK(c, event_new(c, &s->ev_plan));
+        HIPCHK(c, event_new(c, &s->ev_census));
+        HIPCHK(c, event_new(c, &s->ev_fork));
+        HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&s->d_words), 256));
+        HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&s->d_share_stats), 256));
+        HIPCHK(c, hipMemset(s->d_share_stats, 0, 256));
+        HIPCHK(c, pin_alloc(c, reinterpret_cast<void**>(&s->h_census), 64));
+    }
+    s->bound = true; s->stream = st; s->tick = ++c->slot_tick;
+    *out = s;
+    return AG_OK;
+}
+// end of a call that used the slot: later calls on OTHER streams that take the slot over wait for this point
+void slot_release(CallSlot* s, hipStream_t st, bool capturing) {
+    if (capturing || !s || !s->ev_done) return;
+    if (hipEventRecord(s->ev_done, st) == hipSuccess) s->have_done = true;
+}
+// is a call of another slot still running on the GPU?  (then this caller is pipelining calls over streams)
+bool other_slot_busy(ag_ctx* c, const CallSlot* me) {
+    bool busy = false;
+    for (CallSlot& k : c->slots)
+        if (&k != me && k.bound && k.have_done) {
+            if (hipEventQuery(k.ev_done) == hipErrorNotReady) busy = true;
+            (void)hipGetLastError();
+        }
+    return busy;
+}
+void slot_destroy(ag_ctx* c, CallSlot& s) {
+    for (hipEvent_t e : {s.ev_plan, s.ev_census, s.ev_done, s.ev_fork}) if (e) (void)hipEventDestroy(e);
+    for (int i = 1; i < CallSlot::kMaxStreams; ++i) {
+        if (s.ev_join[i]) (void)hipEventDestroy(s.ev_join[i]);
+        if (s.aux_stream[i]) (void)hipStreamDestroy(s.aux_stream[i]);
+    }
+    if (s.h_plan_max) (void)hipHostFree(s.h_plan_max);
+    if (s.h_rep_pin) (void)hipHostFree(s.h_rep_pin);
+    if (s.h_census) (void)hipHostFree(s.h_census);
+    if (s.d_words) (void)hipFree(s.d_words);
+    if (s.d_share_stats) (void)hipFree(s.d_share_stats);
+    if (s.d_repeat) (void)hipFree(s.d_repeat);
+    if (s.d_plan) (void)hipFree(s.d_plan);
+    if (s.slab.base) (void)hipFree(s.slab.base);
+    s = CallSlot();
+}
 
 void prof_mark(void* vc, int fam, int phase) {
     ag_ctx* c = static_cast<ag_ctx*>(vc);
@@ -303,14 +400,14 @@ struct Work {
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
-int ensure_slab(ag_ctx* c, size_t bytes) {
-    c->d_share_nns = nullptr;                              // pointed into the workspace that is re-carved now
-    if (c->slab.cap >= bytes) { c->slab.used = 0; return AG_OK; }
-    if (c->slab.base) HIPCHK(c, hipFree(c->slab.base));
-    c->slab.base = nullptr; c->slab.cap = 0;
+int ensure_slab(ag_ctx* c, CallSlot& sl, size_t bytes) {
+    Slab& slab = sl.slab;
+    if (slab.cap >= bytes) { slab.used = 0; return AG_OK; }
+    if (slab.base) HIPCHK(c, dev_free(c, slab.base));
+    slab.base = nullptr; slab.cap = 0;
     const size_t want = round_up(bytes + (bytes >> 3), 1 << 20);
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->slab.base), want));
-    c->slab.cap = want; c->slab.used = 0;
+    HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&slab.base), want));
+    slab.cap = want; slab.used = 0;
     return AG_OK;
 }
 
@@ -327,10 +424,9 @@ size_t work_bytes(int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices
 }
 
 // carve one workspace from the slab (which must already be large enough; see work_bytes)
-int carve_work(ag_ctx* c, Work& w, int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices, bool own_edges,
+int carve_work(ag_ctx* c, Slab& s, Work& w, int Bc, int N, int n_inst, int edge_cap, int c_cap, int slices, bool own_edges,
                bool roll, bool own_group, int N_o, int ell_stride) {
     const size_t rows = (size_t)Bc * N;
-    Slab& s = c->slab;
     w.g.node_in = s.take<float>(rows * NODE_IN);
     w.g.feat12 = s.take<float>(rows * F15_PITCH);            // pitch 12 (n_his 4) or 16 (n_his 5, forward path)
     w.g.group = own_group ? s.take<float>(rows * n_inst) : nullptr;
@@ -450,7 +546,7 @@ int run_model(ag_ctx* c, const GraphBufs& g, float* pred_pos, float* pred_motion
 // ACTIVE precision mode on a 2-particle, 2-edge graph {(0,0),(1,1)} - bitwise what k_edge_enc produces for such edges.
 int compute_self_rows(ag_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
-    if (!c->d_cself) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_cself), 256 * NFP * 4));
+    if (!c->d_cself) HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&c->d_cself), 256 * NFP * 4));
     struct Mini { float node_in[2 * NODE_IN]; float feat12[2 * F15_PITCH]; float group[2]; int recv[2]; int send[2]; int n_edges; int pad; } h{};
     h.node_in[0] = 1.f; h.node_in[6] = 1.f;                         // object particle
     h.node_in[NODE_IN + 1] = 1.f; h.node_in[NODE_IN + 6] = 1.f;     // tool particle
@@ -505,10 +601,7 @@ int ag_ctx_create(int32_t device_id, const ag_dims* dims, ag_ctx** out) {
                     "(rel_dim 20) - got nf %d, n_his %d, in_dim %d, rel_dim %d", dims->nf, dims->n_his, dims->in_dim, dims->rel_dim);
     if (dims->pstep < 1) return fail(c, AG_ERR_INVALID, "pstep must be >= 1");
     HIPCHK(c, hipSetDevice(device_id));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_w), (size_t)WeightLayout::TOTAL * 4));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_overflow), 256));
-    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_share_stats), 256));
-    HIPCHK(c, hipMemset(c->d_share_stats, 0, 256));
+    HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&c->d_w), (size_t)WeightLayout::TOTAL * 4));
 #ifdef AG_DIAG
     c->diag = diag_create();
 #endif
@@ -523,25 +616,12 @@ int ag_ctx_destroy(ag_ctx* c) {
 #endif
     for (auto& p : c->prof_live) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
-    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-    if (c->h_plan_max) (void)hipHostFree(c->h_plan_max);
-    if (c->h_rep_pin) (void)hipHostFree(c->h_rep_pin);
+    for (CallSlot& k : c->slots) slot_destroy(c, k);
     if (c->d_base_cache) (void)hipFree(c->d_base_cache);
-    for (int i = 1; i < ag_ctx::kMaxStreams; ++i) {
-        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
-        if (c->aux_stream[i]) (void)hipStreamDestroy(c->aux_stream[i]);
-    }
     if (c->d_w) (void)hipFree(c->d_w);
     if (c->d_wb3) (void)hipFree(c->d_wb3);
     if (c->d_wlat) (void)hipFree(c->d_wlat);
-    if (c->d_overflow) (void)hipFree(c->d_overflow);
-    if (c->d_share_stats) (void)hipFree(c->d_share_stats);
     if (c->d_cself) (void)hipFree(c->d_cself);
-    if (c->d_repeat) (void)hipFree(c->d_repeat);
-    if (c->d_plan) (void)hipFree(c->d_plan);
-    if (c->slab.base) (void)hipFree(c->slab.base);
     delete c;
     return AG_OK;
 }
@@ -602,13 +682,19 @@ int ag_ctx_launch_counts(ag_ctx* c, int64_t* out2) {
     return AG_OK;
 }
 
+int ag_ctx_alloc_counts(ag_ctx* c, int64_t* out1) {
+    if (!c || !out1) return AG_ERR_INVALID;
+    out1[0] = c->n_allocs;
+    return AG_OK;
+}
+
 int ag_ctx_share_counts(ag_ctx* c, int64_t* out3) {
     if (!c || !out3) return AG_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
     unsigned long long h[2] = {0, 0};
     int nns = 0;
-    HIPCHK(c, hipMemcpy(h, c->d_share_stats, sizeof h, hipMemcpyDeviceToHost));
+    if (c->slots[c->last_slot].d_share_stats) HIPCHK(c, hipMemcpy(h, c->slots[c->last_slot].d_share_stats, sizeof h, hipMemcpyDeviceToHost));
     if (c->d_share_nns) HIPCHK(c, hipMemcpy(&nns, c->d_share_nns, 4, hipMemcpyDeviceToHost));
     out3[0] = nns; out3[1] = (int64_t)h[0]; out3[2] = (int64_t)h[1];
     return AG_OK;
@@ -660,7 +746,7 @@ int ag_ctx_load_weights(ag_ctx* c, const float* const* t, int32_t n) {
         pack_layer_b3(ph(47), t[16], NF, 0, NF, NF, t[17], 5);
         pack_layer_b3(ph(52), t[18], NF, 0, NF, NF, t[19], 5);
         pack_layer_b3(ph(57), t[20], NF, 0, 3, NF, t[21], 1);
-        if (!c->d_wb3) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wb3), img.size() * 2));
+        if (!c->d_wb3) HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&c->d_wb3), img.size() * 2));
         HIPCHK(c, hipMemcpy(c->d_wb3, img.data(), img.size() * 2, hipMemcpyHostToDevice));
     }
     if (c->dims.n_his == 4) {   // latency-mode image
@@ -676,7 +762,7 @@ int ag_ctx_load_weights(ag_ctx* c, const float* const* t, int32_t n) {
         pack_layer_lat(L + lat_weights_offset(7), t[16], NF, 0, NF, NF, t[17], false);            // predictor 0
         pack_layer_lat(L + lat_weights_offset(8), t[18], NF, 0, NF, NF, t[19], false);            // predictor 1
         pack_layer_lat(L + lat_weights_offset(9), t[20], NF, 0, 3, NF, t[21], true);              // predictor 2 (3 outputs)
-        if (!c->d_wlat) HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_wlat), wl.size() * 4));
+        if (!c->d_wlat) HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&c->d_wlat), wl.size() * 4));
         HIPCHK(c, hipMemcpy(c->d_wlat, wl.data(), wl.size() * 4, hipMemcpyHostToDevice));
     }
     c->have_w = true;
@@ -696,19 +782,24 @@ int ag_build_edges(ag_ctx* c, void* stream, const float* d_pos, const uint8_t* d
     const int slices = pick_slices(c, B, N);
     const size_t rows = (size_t)B * N;
     const int ell_stride = edge_ell_stride(N, topk);
-    rc = ensure_slab(c, rows * (size_t)(ell_stride + 1) * 4 + (size_t)B * (slices + 1) * 4 + 4096);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CallSlot* sl = nullptr;
+    rc = slot_acquire(c, st, false, &sl);
+    if (rc) return rc;
+    rc = ensure_slab(c, *sl, rows * (size_t)(ell_stride + 1) * 4 + (size_t)B * (slices + 1) * 4 + 4096);
     if (rc) return rc;
     EdgeArgs a{};
     a.pos = d_pos; a.pos_bstride = (long)N * 3; a.mask = d_mask; a.tool = d_tool; a.thr_vec = d_thr_vec; a.thr = thr;
     a.B = B; a.N = N; a.topk = topk; a.cta = cta ? 1 : 0; a.edge_cap = edge_cap; a.slices = slices;
-    a.ell = c->slab.take<int>(rows * (size_t)std::max(1, ell_stride));
-    a.deg = c->slab.take<int>(rows);
-    a.slice_tot = c->slab.take<int>((size_t)B * slices);
-    a.cta_flag = c->slab.take<int>(B);
+    a.ell = sl->slab.take<int>(rows * (size_t)std::max(1, ell_stride));
+    a.deg = sl->slab.take<int>(rows);
+    a.slice_tot = sl->slab.take<int>((size_t)B * slices);
+    a.cta_flag = sl->slab.take<int>(B);
     a.recv = d_recv; a.send = d_send; a.row_ptr = d_row_ptr; a.n_edges = d_n_edges; a.overflow = nullptr;
     a.max_nR = edge_cap; a.zero_on_overflow = 0; a.block_min_rows = c->opt.edge_block_min;
-    c->prof_stream = static_cast<hipStream_t>(stream);
-    HIPCHK(c, launch_edge_build(a, static_cast<hipStream_t>(stream), prof_mark, c));
+    c->prof_stream = st;
+    HIPCHK(c, launch_edge_build(a, st, prof_mark, c));
+    slot_release(sl, st, false);
     return AG_OK;
 }
 
@@ -724,20 +815,25 @@ int ag_build_edges_single(ag_ctx* c, void* stream, const float* d_pos, const uin
     HIPCHK(c, hipSetDevice(c->device));
     const int slices = pick_slices(c, 1, N);
     const int ell_stride = edge_ell_stride(N, topk);
-    rc = ensure_slab(c, (size_t)N * (size_t)(ell_stride + 1) * 4 + (size_t)(slices + 1) * 4 + 4096);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CallSlot* sl = nullptr;
+    rc = slot_acquire(c, st, false, &sl);
+    if (rc) return rc;
+    rc = ensure_slab(c, *sl, (size_t)N * (size_t)(ell_stride + 1) * 4 + (size_t)(slices + 1) * 4 + 4096);
     if (rc) return rc;
     EdgeArgs a{};
     a.pos = d_pos; a.pos_bstride = (long)N * 3; a.mask = d_mask; a.tool = d_tool; a.thr_vec = nullptr; a.thr = cull_radius;
     a.thr2_override = thr2; a.use_thr2 = 1;
     a.B = 1; a.N = N; a.topk = topk; a.cta = cta ? 2 : 0; a.edge_cap = edge_cap; a.slices = slices;
-    a.ell = c->slab.take<int>((size_t)N * (size_t)std::max(1, ell_stride));
-    a.deg = c->slab.take<int>(N);
-    a.slice_tot = c->slab.take<int>(slices);
-    a.cta_flag = c->slab.take<int>(1);
+    a.ell = sl->slab.take<int>((size_t)N * (size_t)std::max(1, ell_stride));
+    a.deg = sl->slab.take<int>(N);
+    a.slice_tot = sl->slab.take<int>(slices);
+    a.cta_flag = sl->slab.take<int>(1);
     a.recv = d_recv; a.send = d_send; a.row_ptr = d_row_ptr; a.n_edges = d_n_edges; a.overflow = nullptr;
     a.max_nR = edge_cap; a.zero_on_overflow = 0; a.block_min_rows = c->opt.edge_block_min;
-    c->prof_stream = static_cast<hipStream_t>(stream);
-    HIPCHK(c, launch_edge_build(a, static_cast<hipStream_t>(stream), prof_mark, c));
+    c->prof_stream = st;
+    HIPCHK(c, launch_edge_build(a, st, prof_mark, c));
+    slot_release(sl, st, false);
     return AG_OK;
 }
 
@@ -755,19 +851,24 @@ int ag_edges_apply_tool_rule(ag_ctx* c, void* stream, const float* d_pos, const 
         return fail(c, AG_ERR_INVALID, "ag_edges_apply_tool_rule: input and output arrays must differ");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t pairs = (size_t)N * (size_t)std::max(1, n_tools);
-    int rc = ensure_slab(c, pairs * 6 + (size_t)(N + n_tools + 16) * 4 + 8 * 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CallSlot* sl = nullptr;
+    int rc = slot_acquire(c, st, false, &sl);
+    if (rc) return rc;
+    rc = ensure_slab(c, *sl, pairs * 6 + (size_t)(N + n_tools + 16) * 4 + 8 * 256);
     if (rc) return rc;
     RuleArgs a{};
     a.pos = d_pos; a.mask = d_mask; a.tool = d_tool; a.subset = d_subset; a.send_in = d_send_in; a.row_ptr_in = d_row_ptr_in;
     a.N = N; a.n_tools = n_tools; a.edge_cap = edge_cap; a.use_knn = (kNN < 1.0 && kNN > 0.0) ? 1 : 0; a.kNN = kNN;   // graph.py:156
-    a.tlist = c->slab.take<int>(std::max(1, n_tools));
-    a.misc = c->slab.take<int>(16);
-    a.pdis = c->slab.take<float>(pairs);
-    a.keep = c->slab.take<uint8_t>(pairs);
-    a.kept = c->slab.take<uint8_t>(pairs);
-    a.deg = c->slab.take<int>(N);
+    a.tlist = sl->slab.take<int>(std::max(1, n_tools));
+    a.misc = sl->slab.take<int>(16);
+    a.pdis = sl->slab.take<float>(pairs);
+    a.keep = sl->slab.take<uint8_t>(pairs);
+    a.kept = sl->slab.take<uint8_t>(pairs);
+    a.deg = sl->slab.take<int>(N);
     a.recv = d_recv; a.send = d_send; a.row_ptr = d_row_ptr; a.n_out = d_n_out;
-    HIPCHK(c, launch_tool_rule(a, static_cast<hipStream_t>(stream)));
+    HIPCHK(c, launch_tool_rule(a, st));
+    slot_release(sl, st, false);
     return AG_OK;
 }
 
@@ -788,15 +889,18 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
     const int c_cap = (int)round_up(edge_cap, 256);
     const int Bc = clamp_chunk_for_offsets(auto_chunk(c, B, N), N, c_cap);
     Work w{};
-    int rc = ensure_slab(c, work_bytes(Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0) + (size_t)B * 4 + 512);
+    CallSlot* sl = nullptr;
+    int rc = slot_acquire(c, st, false, &sl);
     if (rc) return rc;
-    rc = carve_work(c, w, Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0);
+    rc = ensure_slab(c, *sl, work_bytes(Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0) + (size_t)B * 4 + 512);
+    if (rc) return rc;
+    rc = carve_work(c, sl->slab, w, Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0);
     if (rc) return rc;
     // the caller's graphs may be overflowed (true count > edge_cap, indices never written): guard, then report
-    int* n_eff = c->slab.take<int>((size_t)B);
-    if (c->slab.used > c->slab.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
-    HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, st));
-    HIPCHK(c, launch_edge_guard(d_n_edges, B, edge_cap, n_eff, c->d_overflow, st));
+    int* n_eff = sl->slab.take<int>((size_t)B);
+    if (sl->slab.used > sl->slab.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
+    HIPCHK(c, hipMemsetAsync(sl->d_words, 0, 4, st));
+    HIPCHK(c, launch_edge_guard(d_n_edges, B, edge_cap, n_eff, sl->d_words, st));
     for (int b0 = 0; b0 < B; b0 += Bc) {
         const int nb = std::min(Bc, B - b0);
         GraphBufs g = w.g;
@@ -812,8 +916,9 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
         if (rc) return rc;
     }
     int seen = 0;
-    HIPCHK(c, hipMemcpyAsync(&seen, c->d_overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&seen, sl->d_words, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    slot_release(sl, st, false);
     if (seen > 0) return fail(c, AG_ERR_MAX_NR, "Exceeds max dims: a graph had %d edges, edge_cap=%d", seen, edge_cap);
     return AG_OK;
 }
@@ -859,9 +964,14 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     // an event or wait - no polling of the plan's maxima, no prefix sharing (both only save work; results are the same)
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap_status) == hipSuccess && cap_status == hipStreamCaptureStatusActive;
-    // the previous rollout call of this context may still be running on another stream: its workspace, plan and repeat tables are
-    // this call's too, so this stream waits for it (same stream: stream order already does)
-    if (!capturing && c->have_done && c->last_stream != st) HIPCHK(c, hipStreamWaitEvent(st, c->ev_done, 0));
+    // workspace, plans and read-back buffers of this call: the slot of the caller's stream (calls on other streams have their own
+    // and may still be running; a taken-over slot has been waited for)
+    CallSlot* slp = nullptr;
+    rc = slot_acquire(c, st, capturing, &slp);
+    if (rc) return rc;
+    CallSlot& sl = *slp;
+    c->last_slot = (int)(slp - c->slots);
+    c->d_share_nns = nullptr;                                // pointed into a workspace of an earlier call
     HIPCHK(c, hipMemsetAsync(d_state_seqs, 0, (size_t)p->B * p->H * p->N_o * 3 * 4, st));   // forward_dynamics.py:32
 
     const int k = std::min(N, p->topk);
@@ -879,8 +989,11 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         const int full = auto_chunk(c, p->B, N);
         if (c->n_streams == 2 && (p->B + full - 1) / full >= 8) ns = 4;
     }
-    if ((long)p->B * N < 65536) ns = 1;   // small batches are dispatch-bound: a second stream only doubles the launches
+    if ((long)p->B * N < c->opt.stream_min_rows) ns = 1;   // small batches are dispatch-bound: a second stream only doubles the launches
                                           // (rope 64 x 301: 10.8 ms on one stream, 12.9 ms on two)
+    // a caller that pipelines independent calls over several streams (the planner's chunk loop) already fills the chip across
+    // calls: no fork inside a call that starts while a call of another stream is still running
+    if (ns > 1 && !capturing && c->opt.pipeline_fork == 0 && other_slot_busy(c, &sl)) ns = 1;
     if (c->opt.streams > 0) ns = std::min(c->opt.streams, (int)ag_ctx::kMaxStreams);
     // per-kernel event times are only meaningful without cross-stream interference; bit 30 of the mask keeps the
     // streams (the durations then include whatever the other stream ran beside the kernel)
@@ -915,7 +1028,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     const bool sort_on = c->opt.repeat_sort != 0;
     const int n_chunks_all = (p->B + Bc - 1) / Bc;
     int* h_cand = nullptr;
-    // device plan: pointers into c->d_plan
+    // device plan: pointers into sl.d_plan
     const int R = src.max_repeat;
     int *pl_repeat = nullptr, *pl_cand = nullptr, *pl_live = nullptr, *pl_rows = nullptr, *pl_sums = nullptr;
     float *pl_xz = nullptr, *pl_delta = nullptr;
@@ -934,122 +1047,14 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     // tool particle's radius", graph.py:276-286 - the very contact that is tested; shipped cloth pushes just start on the cloth)
     bool prefix = c->opt.share_prefix != 0 && p->y_mode == 0 && !d_obj_mask && p->M <= 8 && !capturing;
     if (c->opt.share_prefix < 0 && (p->B < 64 || (long)p->B * N < 32768)) prefix = false;
-    ag_ctx::BaseKey base_key_now;
-    memset(&base_key_now, 0, sizeof base_key_now);
-    bool census = false, base_cached = false;
     int R_base = 0;                                          // steps of the base rollout = the largest repeat of look-ahead step 0
     if (prefix) {
         if (dev_plan) R_base = R;
         else for (int b = 0; b < p->B; ++b) R_base = std::max(R_base, (int)h_repeat[(size_t)b * p->H]);
         if (R_base < 1) prefix = false;
     }
-    // host plan: repeat counts -> per chunk and look-ahead step the launch order (descending repeat, stable), both uploaded
-    auto host_plan = [&](const int32_t* rep_src) -> int {
-        if (c->repeat_cap < 2 * nrep) {
-            if (c->d_repeat) HIPCHK(c, hipFree(c->d_repeat));
-            c->d_repeat = nullptr; c->repeat_cap = 0;
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_repeat), 2 * nrep * 4));
-            c->repeat_cap = 2 * nrep;
-        }
-        c->h_repeat.resize(2 * nrep);
-        std::copy(rep_src, rep_src + nrep, c->h_repeat.begin());
-        h_repeat = c->h_repeat.data();
-        h_cand = c->h_repeat.data() + nrep;                  // [li][slot] -> candidate
-        for (int li = 0; li < p->H; ++li)
-            for (int b0 = 0; b0 < p->B; b0 += Bc) {
-                const int nb = std::min(Bc, p->B - b0);
-                int* seg = h_cand + (size_t)li * p->B + b0;
-                for (int b = 0; b < nb; ++b) seg[b] = b0 + b;
-                if (sort_on)
-                    std::stable_sort(seg, seg + nb, [&](int x, int y) { return h_repeat[(size_t)x * p->H + li] > h_repeat[(size_t)y * p->H + li]; });
-            }
-        HIPCHK(c, hipMemcpyAsync(c->d_repeat, h_repeat, 2 * nrep * 4, hipMemcpyHostToDevice, st));
-        return AG_OK;
-    };
-    if (!dev_plan) {
-        rc = host_plan(h_repeat);                            // (prefix sharing plans again, with the forwards that are left)
-        if (rc) return rc;
-        c->fwd_executed = 0; c->fwd_needed = 0;
-        for (size_t i = 0; i < nrep; ++i) c->fwd_needed += std::max(0, h_repeat[i]);
-    } else {
-        // Device plan: one kernel decodes the actions (plan_utils.py:11-20, forward_dynamics.py:42-75), orders every
-        // chunk's candidates by action_repeat and tabulates how many are live at every step; the launches below take their
-        // live counts from that table (device memory), so nothing of the actions ever crosses to the host.
-        const size_t tab = (size_t)n_chunks_all * p->H * (R + 2);
-        const size_t n_int = 2 * nrep + 2 * tab + (size_t)n_chunks_all * p->H * 3;
-        const size_t n_flt = nrep * p->M * 5;
-        const size_t bytes = round_up(n_int * 4, 256) + n_flt * 4;
-        if (c->plan_cap < bytes) {
-            if (c->d_plan) HIPCHK(c, hipFree(c->d_plan));
-            c->d_plan = nullptr; c->plan_cap = 0;
-            HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_plan), bytes + (bytes >> 2)));
-            c->plan_cap = bytes + (bytes >> 2);
-        }
-        pl_repeat = reinterpret_cast<int*>(c->d_plan); pl_cand = pl_repeat + nrep; pl_live = pl_cand + nrep;
-        pl_rows = pl_live + tab; pl_sums = pl_rows + tab;
-        pl_xz = reinterpret_cast<float*>(c->d_plan + round_up(n_int * 4, 256)); pl_delta = pl_xz + nrep * p->M * 2;
-        RollPlan rp{};
-        rp.action = src.d_action; rp.push_length = src.push_length; rp.M = p->M;
-        for (int kk = 1; kk < p->M; ++kk) rp.tool_off[kk] = src.h_tool_off[kk];
-        rp.B = p->B; rp.H = p->H; rp.Bc = Bc; rp.N = N; rp.max_repeat = R;
-        rp.decoded = src.d_action_seqs; rp.eef_xz = pl_xz; rp.eef_delta = pl_delta; rp.repeat = pl_repeat; rp.cand = pl_cand;
-        rp.live = pl_live; rp.rows = pl_rows; rp.sums = pl_sums; rp.flags = d_overflow_flag; rp.sort = sort_on ? 1 : 0;
-        rp.maxrep = pl_sums + (size_t)n_chunks_all * p->H * 2;
-        HIPCHK(c, launch_roll_plan(rp, st));
-        // Every (chunk, look-ahead step)'s own maximum comes back into pinned host memory behind an event - asynchronously:
-        // nothing waits for it.  The enqueue loop below polls the event (hipEventQuery) and, once it has fired, stops enqueuing
-        // a look-ahead step's repeats at that maximum instead of at the caller's bound (whose surplus steps would find no live
-        // slot: full grids of workgroups that exit).  Until it fires the loop goes by the bound, as before.
-        const size_t n_max = (size_t)n_chunks_all * p->H;
-        if (c->plan_max_cap < n_max) {
-            if (c->h_plan_max) HIPCHK(c, hipHostFree(c->h_plan_max));
-            c->h_plan_max = nullptr; c->plan_max_cap = 0;
-            HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_plan_max), (n_max + 64) * 4, hipHostMallocDefault));
-            c->plan_max_cap = n_max + 64;
-        }
-        if (!c->ev_plan) HIPCHK(c, hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
-        if (!capturing) {
-            HIPCHK(c, hipMemcpyAsync(c->h_plan_max, rp.maxrep, n_max * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipEventRecord(c->ev_plan, st));
-        }
-        d_eef_xz = pl_xz; d_eef_delta = pl_delta;
-        c->d_plan_sums = pl_sums; c->plan_sums_n = n_chunks_all * p->H;
-        c->fwd_executed = -1; c->fwd_needed = -1;
-    }
-    if (prefix && c->opt.share_prefix < 0) {
-        // Automatic mode: is the base rollout worth its latency-bound forwards?  Census of the FIRST forward (its graph needs
-        // the start state only): how many candidates touch at once.  Sharing is kept when enough of them do not - a batch of
-        // pushes aimed at the object (every candidate in contact from the first forward on) steps all of them anyway.  One
-        // tiny kernel and one wait, before any other work of the call is enqueued.
-        ContactPlan cp{};
-        cp.base_states = d_state0; cp.R = 1; cp.eef_xz = d_eef_xz; cp.eef_delta = d_eef_delta; cp.repeat = dev_plan ? pl_repeat : c->d_repeat;
-        cp.B = p->B; cp.H = p->H; cp.N_o = p->N_o; cp.M = p->M; cp.thr = p->adj_thresh;
-        cp.grip = p->gripper_offset; cp.grip_on = p->gripper_enable;
-        int* d_cnt = reinterpret_cast<int*>(c->d_share_stats) + 8;          // four ints behind the share counters
-        cp.count = d_cnt;
-        int h_cnt[4] = {0, 0, 0, 0};
-        HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, st));
-        HIPCHK(c, launch_contact_plan(cp, st));
-        // ... and is the base rollout of an earlier call still good?  (same model and task scalars: compared here; same start
-        // state: compared bit for bit on the device, [3] = words that differ)
-        memset(&base_key_now, 0, sizeof base_key_now);        // (padding bytes too: the keys are compared with memcmp)
-        base_key_now.N_o = p->N_o; base_key_now.M = p->M; base_key_now.topk = p->topk; base_key_now.cta = p->connect_tools_all;
-        base_key_now.max_nR = p->max_nR; base_key_now.n_his = n_his; base_key_now.precision = c->precision;
-        base_key_now.pstep = c->dims.pstep; base_key_now.grip_on = p->gripper_enable; base_key_now.thr = p->adj_thresh;
-        base_key_now.grip = p->gripper_offset; base_key_now.phys = p->physics_param; base_key_now.clamp = c->dims.motion_clamp;
-        base_key_now.phys_vec = d_phys_vec; base_key_now.weights_version = c->weights_version;
-        const bool key_ok = c->base_cache_R >= 1 && !d_phys_vec && memcmp(&base_key_now, &c->base_key, sizeof base_key_now) == 0;
-        if (key_ok) HIPCHK(c, launch_count_diff(d_state0, c->d_base_cache, (long)p->N_o * 3, d_cnt + 3, st));
-        HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        R_base = std::min(R_base, std::max(1, h_cnt[2]));     // the batch's own maximum (the device plan only knows the bound)
-        // worth it when enough candidates are still free at the first forward to pay for the base rollout's latency-bound
-        // forwards (each costs about as much as eight candidate-forwards of a full launch)
-        if (h_cnt[1] - h_cnt[0] < std::max(64, 8 * R_base)) prefix = false;
-        census = true;
-        base_cached = prefix && key_ok && h_cnt[3] == 0 && c->base_cache_R >= R_base;
-    }
-    const bool loop_dev = dev_plan && !prefix;               // the enqueue loop reads its live counts from the device plan's tables
+    const bool auto_prefix = prefix && c->opt.share_prefix < 0;
+    const bool base_in_ctx = auto_prefix && !d_phys_vec;      // automatic mode: the base rollout lives in the context, for later calls
 
     // Shared first forward (Options::share_first).  dynamics() broadcasts ONE start state to all candidates with a constant
     // history (forward_dynamics.py:25), then builds and encodes every candidate's graph separately (:125, model.py:303).  At
@@ -1073,29 +1078,216 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     const int base_slices = pick_slices(c, 1, p->N_o);
     const size_t base_bytes = !share ? 0 : (size_t)base_cap * (NFP + 3) * 4 + (size_t)p->N_o * (NODE_IN + F15_PITCH + 2) * 4 +
                                            2 * (size_t)p->N_o + (size_t)(base_slices + 8) * 4 + 24 * 256;
-    const size_t prefix_bytes = !prefix ? 0 : ((size_t)(R_base + 1) * (p->N_o * 3 + 1) + 2 * nrep + p->B + 5 * p->M + 64) * 4 + 16 * 256;
+    // (sized before the census below may still switch the sharing off: its scratch is carved first)
+    const size_t prefix_bytes = !prefix ? 0 : ((base_in_ctx ? 0 : (size_t)(R_base + 1) * (p->N_o * 3 + 1)) + 2 * nrep + p->B + 5 * p->M + 64) * 4 + 16 * 256;
     const size_t wb = work_bytes(Ba, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
-    rc = ensure_slab(c, wb * ns + base_bytes + prefix_bytes);
+    rc = ensure_slab(c, sl, wb * ns + base_bytes + prefix_bytes);
     if (rc) return rc;
+    float* b_states = nullptr; float* b_y = nullptr;
+    int* b_rep_eff = nullptr; int* b_start = nullptr; float* b_eef = nullptr; int* b_zero = nullptr;
+    if (prefix) {
+        if (!base_in_ctx) { b_states = sl.slab.take<float>((size_t)(R_base + 1) * p->N_o * 3); b_y = sl.slab.take<float>(R_base + 1); }
+        b_rep_eff = sl.slab.take<int>(nrep); b_start = sl.slab.take<int>(p->B);
+        b_eef = sl.slab.take<float>((size_t)5 * p->M);       // parked tool: xz (M,2), delta (M,3)
+        b_zero = sl.slab.take<int>(1);
+        if (sl.slab.used > sl.slab.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
+        if (sl.rep_pin_cap < 2 * nrep + 8) {                 // pinned read-back of the contact plan: [forwards left | repeat | flag, census x4]
+            if (sl.h_rep_pin) HIPCHK(c, pin_free(c, sl.h_rep_pin));
+            sl.h_rep_pin = nullptr; sl.rep_pin_cap = 0;
+            HIPCHK(c, pin_alloc(c, reinterpret_cast<void**>(&sl.h_rep_pin), (2 * nrep + 64) * 4));
+            sl.rep_pin_cap = 2 * nrep + 64;
+        }
+    }
+
+    // host plan: repeat counts -> per chunk and look-ahead step the launch order (descending repeat, stable), both uploaded
+    auto host_plan = [&](const int32_t* rep_src) -> int {
+        if (sl.repeat_cap < 2 * nrep) {
+            if (sl.d_repeat) HIPCHK(c, dev_free(c, sl.d_repeat));
+            sl.d_repeat = nullptr; sl.repeat_cap = 0;
+            HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&sl.d_repeat), (2 * nrep + (nrep >> 2)) * 4));
+            sl.repeat_cap = 2 * nrep + (nrep >> 2);
+        }
+        sl.h_repeat.resize(2 * nrep);
+        if (rep_src != sl.h_repeat.data()) std::copy(rep_src, rep_src + nrep, sl.h_repeat.begin());
+        h_repeat = sl.h_repeat.data();
+        h_cand = sl.h_repeat.data() + nrep;                  // [li][slot] -> candidate
+        for (int li = 0; li < p->H; ++li)
+            for (int b0 = 0; b0 < p->B; b0 += Bc) {
+                const int nb = std::min(Bc, p->B - b0);
+                int* seg = h_cand + (size_t)li * p->B + b0;
+                for (int b = 0; b < nb; ++b) seg[b] = b0 + b;
+                if (sort_on)
+                    std::stable_sort(seg, seg + nb, [&](int x, int y) { return h_repeat[(size_t)x * p->H + li] > h_repeat[(size_t)y * p->H + li]; });
+            }
+        HIPCHK(c, hipMemcpyAsync(sl.d_repeat, h_repeat, 2 * nrep * 4, hipMemcpyHostToDevice, st));
+        return AG_OK;
+    };
+    if (!dev_plan) {
+        rc = host_plan(h_repeat);                            // (prefix sharing plans again, with the forwards that are left)
+        if (rc) return rc;
+        c->fwd_executed = 0; c->fwd_needed = 0;
+        for (size_t i = 0; i < nrep; ++i) c->fwd_needed += std::max(0, h_repeat[i]);
+    } else {
+        // Device plan: one kernel decodes the actions (plan_utils.py:11-20, forward_dynamics.py:42-75), orders every
+        // chunk's candidates by action_repeat and tabulates how many are live at every step; the launches below take their
+        // live counts from that table (device memory), so nothing of the actions ever crosses to the host.
+        const size_t tab = (size_t)n_chunks_all * p->H * (R + 2);
+        const size_t n_int = 2 * nrep + 2 * tab + (size_t)n_chunks_all * p->H * 3;
+        const size_t n_flt = nrep * p->M * 5;
+        const size_t bytes = round_up(n_int * 4, 256) + n_flt * 4;
+        if (sl.plan_cap < bytes) {
+            if (sl.d_plan) HIPCHK(c, dev_free(c, sl.d_plan));
+            sl.d_plan = nullptr; sl.plan_cap = 0;
+            HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&sl.d_plan), bytes + (bytes >> 2)));
+            sl.plan_cap = bytes + (bytes >> 2);
+        }
+        pl_repeat = reinterpret_cast<int*>(sl.d_plan); pl_cand = pl_repeat + nrep; pl_live = pl_cand + nrep;
+        pl_rows = pl_live + tab; pl_sums = pl_rows + tab;
+        pl_xz = reinterpret_cast<float*>(sl.d_plan + round_up(n_int * 4, 256)); pl_delta = pl_xz + nrep * p->M * 2;
+        RollPlan rp{};
+        rp.action = src.d_action; rp.push_length = src.push_length; rp.M = p->M;
+        for (int kk = 1; kk < p->M; ++kk) rp.tool_off[kk] = src.h_tool_off[kk];
+        rp.B = p->B; rp.H = p->H; rp.Bc = Bc; rp.N = N; rp.max_repeat = R;
+        rp.decoded = src.d_action_seqs; rp.eef_xz = pl_xz; rp.eef_delta = pl_delta; rp.repeat = pl_repeat; rp.cand = pl_cand;
+        rp.live = pl_live; rp.rows = pl_rows; rp.sums = pl_sums; rp.flags = d_overflow_flag; rp.sort = sort_on ? 1 : 0;
+        rp.maxrep = pl_sums + (size_t)n_chunks_all * p->H * 2;
+        HIPCHK(c, launch_roll_plan(rp, st));
+        // Every (chunk, look-ahead step)'s own maximum comes back into pinned host memory behind an event - asynchronously:
+        // nothing waits for it.  The enqueue loop below polls the event (hipEventQuery) and, once it has fired, stops enqueuing
+        // a look-ahead step's repeats at that maximum instead of at the caller's bound (whose surplus steps would find no live
+        // slot: full grids of workgroups that exit).  Until it fires the loop goes by the bound, as before.
+        const size_t n_max = (size_t)n_chunks_all * p->H;
+        if (sl.plan_max_cap < n_max) {
+            if (sl.h_plan_max) HIPCHK(c, pin_free(c, sl.h_plan_max));
+            sl.h_plan_max = nullptr; sl.plan_max_cap = 0;
+            HIPCHK(c, pin_alloc(c, reinterpret_cast<void**>(&sl.h_plan_max), (n_max + 64) * 4));
+            sl.plan_max_cap = n_max + 64;
+        }
+        if (!capturing) {
+            HIPCHK(c, hipMemcpyAsync(sl.h_plan_max, rp.maxrep, n_max * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipEventRecord(sl.ev_plan, st));
+        }
+        d_eef_xz = pl_xz; d_eef_delta = pl_delta;
+        c->d_plan_sums = pl_sums; c->plan_sums_n = n_chunks_all * p->H;
+        c->fwd_executed = -1; c->fwd_needed = -1;
+    }
+    const int* d_rep_orig = dev_plan ? pl_repeat : sl.d_repeat;
+    const int rep_bound = dev_plan ? R : 0x7fffffff;          // a device-planned candidate beyond the caller's bound is never captured
+    BaseKey key_now;
+    memset(&key_now, 0, sizeof key_now);                     // (padding bytes too: the keys are compared with memcmp)
+    key_now.N_o = p->N_o; key_now.M = p->M; key_now.topk = p->topk; key_now.cta = p->connect_tools_all;
+    key_now.max_nR = p->max_nR; key_now.n_his = n_his; key_now.precision = c->precision;
+    key_now.pstep = c->dims.pstep; key_now.grip_on = p->gripper_enable; key_now.thr = p->adj_thresh;
+    key_now.grip = p->gripper_offset; key_now.phys = p->physics_param; key_now.clamp = c->dims.motion_clamp;
+    key_now.phys_vec = d_phys_vec; key_now.weights_version = c->weights_version;
+    // censuses that nobody waited for (below): one that has landed and finds enough free candidates lifts the standing "not worth
+    // it" verdict, so that the next call of that shape takes a proper census again
+    for (CallSlot& q : c->slots)
+        if (q.census_pending && !capturing) {
+            if (hipEventQuery(q.ev_census) == hipSuccess) {
+                q.census_pending = false;
+                const int free_now = q.h_census[1] - q.h_census[0], rb = std::min(q.census_R, std::max(1, q.h_census[2]));
+                if (c->decision.decline && c->decision.B == q.census_B && c->decision.H == q.census_H &&
+                    memcmp(&c->decision.key, &q.census_key, sizeof(BaseKey)) == 0 && free_now >= std::max(64, 8 * rb))
+                    c->decision.decline = false;
+            } else (void)hipGetLastError();
+        }
+    bool census = false, base_cached = false, plan_done = false;
+    if (auto_prefix) {
+        // Automatic mode: is the base rollout worth its latency-bound forwards?  Census of the FIRST forward (its graph needs
+        // the start state only): how many candidates touch at once.  Sharing is kept when enough of them do not - a batch of
+        // pushes aimed at the object (every candidate in contact from the first forward on) steps all of them anyway: worth it
+        // when enough candidates are still free at the first forward to pay for the base rollout's latency-bound forwards (each
+        // costs about as much as eight candidate-forwards of a full launch).
+        ContactPlan cen{};
+        cen.base_states = d_state0; cen.R = 1; cen.eef_xz = d_eef_xz; cen.eef_delta = d_eef_delta; cen.repeat = d_rep_orig;
+        cen.B = p->B; cen.H = p->H; cen.N_o = p->N_o; cen.M = p->M; cen.thr = p->adj_thresh;
+        cen.grip = p->gripper_offset; cen.grip_on = p->gripper_enable;
+        int* d_cnt = sl.d_words + 8;                          // [0] touch at the first forward, [1] have a forward to run, [2] max repeat, [3] state words that differ
+        cen.count = d_cnt;
+        // is the base rollout of an earlier call still good?  Same model and task scalars: compared here; same start state:
+        // compared bit for bit on the device ([3])
+        const bool key_ok = c->base_cache_R >= 1 && !d_phys_vec && memcmp(&key_now, &c->base_key, sizeof key_now) == 0;
+        const bool declined = c->decision.decline && c->decision.B == p->B && c->decision.H == p->H &&
+                              memcmp(&key_now, &c->decision.key, sizeof key_now) == 0;
+        if (key_ok) {
+            // A base rollout is kept: census, state compare and the contact plan ALONG THE KEPT ROLLOUT go out together and the
+            // call waits once.  (The planner calls dynamics() 40 times with one start state, plan.py:241-247: calls 2..40 come here.)
+            HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, st));
+            HIPCHK(c, launch_contact_plan(cen, st));
+            HIPCHK(c, launch_count_diff(d_state0, c->d_base_cache, (long)p->N_o * 3, d_cnt + 3, st));
+            ContactPlan cp{};
+            cp.base_states = c->d_base_cache; cp.base_y = c->d_base_cache + (size_t)(c->base_cache_capR + 1) * p->N_o * 3;
+            cp.R = c->base_cache_R; cp.R_bound = rep_bound;
+            cp.eef_xz = d_eef_xz; cp.eef_delta = d_eef_delta; cp.repeat = d_rep_orig;
+            cp.B = p->B; cp.H = p->H; cp.N_o = p->N_o; cp.M = p->M; cp.thr = p->adj_thresh; cp.rep_eff = b_rep_eff; cp.start = b_start;
+            cp.state_seqs = d_state_seqs;
+            HIPCHK(c, launch_contact_plan(cp, st));
+            HIPCHK(c, hipMemcpyAsync(sl.h_rep_pin, b_rep_eff, nrep * 4, hipMemcpyDeviceToHost, st));
+            if (dev_plan) HIPCHK(c, hipMemcpyAsync(sl.h_rep_pin + nrep, pl_repeat, nrep * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipMemcpyAsync(sl.h_rep_pin + 2 * nrep, d_overflow_flag, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipMemcpyAsync(sl.h_rep_pin + 2 * nrep + 1, d_cnt, 16, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipEventRecord(sl.ev_plan, st));
+            HIPCHK(c, hipEventSynchronize(sl.ev_plan));
+            const int* h_cnt = sl.h_rep_pin + 2 * nrep + 1;
+            R_base = std::min(R_base, std::max(1, h_cnt[2]));     // the batch's own maximum (the device plan only knows the bound)
+            census = true;
+            if (h_cnt[3] == 0 && c->base_cache_R >= R_base) { base_cached = true; plan_done = true; }   // a kept base rollout is free: share
+            else {
+                // another start state (or a longer push than the kept rollout covers): what the plan above wrote is void
+                HIPCHK(c, hipMemsetAsync(d_state_seqs, 0, (size_t)p->B * p->H * p->N_o * 3 * 4, st));
+                if (h_cnt[1] - h_cnt[0] < std::max(64, 8 * R_base)) prefix = false;
+            }
+        } else if (declined) {
+            // the last census of this shape found (nearly) every push on the object: no sharing, and no waiting either - a census
+            // goes out that the call does not wait for (read by a later call, above)
+            prefix = false;
+            if (!sl.census_pending) {
+                HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, st));
+                HIPCHK(c, launch_contact_plan(cen, st));
+                HIPCHK(c, hipMemcpyAsync(sl.h_census, d_cnt, 16, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipEventRecord(sl.ev_census, st));
+                sl.census_pending = true; sl.census_B = p->B; sl.census_H = p->H; sl.census_R = R_base;
+                memcpy(&sl.census_key, &key_now, sizeof key_now);
+            }
+        } else {
+            // one tiny kernel and one wait (for it and whatever the caller enqueued on this stream before the call)
+            HIPCHK(c, hipMemsetAsync(d_cnt, 0, 16, st));
+            HIPCHK(c, launch_contact_plan(cen, st));
+            HIPCHK(c, hipMemcpyAsync(sl.h_census + 4, d_cnt, 16, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipEventRecord(sl.ev_plan, st));
+            HIPCHK(c, hipEventSynchronize(sl.ev_plan));
+            const int* h_cnt = sl.h_census + 4;
+            R_base = std::min(R_base, std::max(1, h_cnt[2]));
+            if (h_cnt[1] - h_cnt[0] < std::max(64, 8 * R_base)) prefix = false;
+            census = true;
+        }
+        if (census) {
+            c->decision.decline = !prefix;
+            if (!prefix) { memcpy(&c->decision.key, &key_now, sizeof key_now); c->decision.B = p->B; c->decision.H = p->H; }
+        }
+    }
+    const bool loop_dev = dev_plan && !prefix;               // the enqueue loop reads its live counts from the device plan's tables
+
     Work ws[ag_ctx::kMaxStreams] = {};
     for (int i = 0; i < ns; ++i) {
-        rc = carve_work(c, ws[i], Ba, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
+        rc = carve_work(c, sl.slab, ws[i], Ba, N, 1, edge_cap, edge_cap, slices, true, true, true, p->N_o, ell);
         if (rc) return rc;
     }
     const int* base_send = nullptr; const int* base_deg = nullptr; const float* C_share = nullptr;
-    HIPCHK(c, hipMemsetAsync(c->d_share_stats, 0, 16, st));   // counters of this call (ag_ctx_share_counts)
+    HIPCHK(c, hipMemsetAsync(sl.d_share_stats, 0, 16, st));   // counters of this call (ag_ctx_share_counts)
     if (share) {
-        Slab& sl = c->slab;
-        float* b_C = sl.take<float>((size_t)base_cap * NFP);
-        int* b_send = sl.take<int>(base_cap); int* b_recv = sl.take<int>(base_cap); int* b_ns = sl.take<int>(base_cap);
-        float* b_node_in = sl.take<float>((size_t)p->N_o * NODE_IN);
-        float* b_feat = sl.take<float>((size_t)p->N_o * F15_PITCH);
-        float* b_group = sl.take<float>(p->N_o);
-        int* b_deg = sl.take<int>(p->N_o);
-        uint8_t* b_mask = sl.take<uint8_t>(p->N_o); uint8_t* b_tool = sl.take<uint8_t>(p->N_o);
-        int* b_slice_tot = sl.take<int>(base_slices); int* b_cta = sl.take<int>(1);
-        int* b_n_edges = sl.take<int>(1); int* b_n_ns = sl.take<int>(1);
-        if (sl.used > sl.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
+        Slab& sb = sl.slab;
+        float* b_C = sb.take<float>((size_t)base_cap * NFP);
+        int* b_send = sb.take<int>(base_cap); int* b_recv = sb.take<int>(base_cap); int* b_ns = sb.take<int>(base_cap);
+        float* b_node_in = sb.take<float>((size_t)p->N_o * NODE_IN);
+        float* b_feat = sb.take<float>((size_t)p->N_o * F15_PITCH);
+        float* b_group = sb.take<float>(p->N_o);
+        int* b_deg = sb.take<int>(p->N_o);
+        uint8_t* b_mask = sb.take<uint8_t>(p->N_o); uint8_t* b_tool = sb.take<uint8_t>(p->N_o);
+        int* b_slice_tot = sb.take<int>(base_slices); int* b_cta = sb.take<int>(1);
+        int* b_n_edges = sb.take<int>(1); int* b_n_ns = sb.take<int>(1);
+        if (sb.used > sb.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
         HIPCHK(c, launch_share_prep(d_state0, p->N_o, n_his, b_node_in, b_feat, b_group, b_mask, b_tool, st));
         EdgeArgs be{};
         be.pos = d_state0; be.pos_bstride = (long)p->N_o * 3; be.mask = b_mask; be.tool = b_tool; be.thr = p->adj_thresh;
@@ -1115,26 +1307,26 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     }
     const int* d_start = nullptr; const float* d_base_states = nullptr; const float* d_base_y = nullptr;
     if (prefix) {
-        Slab& sl = c->slab;
-        float* b_states; float* b_y;
-        if (census && !d_phys_vec) {                         // automatic mode: the base rollout lives in the context, for later calls
+        if (base_in_ctx) {
             const size_t need = (size_t)(R_base + 1) * (p->N_o * 3 + 1);
-            if (!base_cached && c->base_cache_cap < need) {
-                if (c->d_base_cache) HIPCHK(c, hipFree(c->d_base_cache));
-                c->d_base_cache = nullptr; c->base_cache_cap = 0; c->base_cache_R = -1;
-                HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->d_base_cache), need * 4));
-                c->base_cache_cap = need;
+            if (!base_cached) {
+                // the kept rollout is about to be replaced: calls of other streams that still read it come first
+                for (CallSlot& q : c->slots)
+                    if (&q != &sl && q.bound && q.have_done) HIPCHK(c, hipStreamWaitEvent(st, q.ev_done, 0));
+                c->base_cache_R = -1;
+                if (c->base_cache_cap < need) {
+                    if (c->d_base_cache) HIPCHK(c, dev_free(c, c->d_base_cache));
+                    c->d_base_cache = nullptr; c->base_cache_cap = 0;
+                    // (room for the longest push the caller's bound allows: a later call with longer pushes re-uses the buffer)
+                    const size_t want = std::max(need, (size_t)((dev_plan ? R : R_base) + 1) * (p->N_o * 3 + 1));
+                    HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&c->d_base_cache), want * 4));
+                    c->base_cache_cap = want;
+                }
+                c->base_cache_capR = (int)(c->base_cache_cap / (p->N_o * 3 + 1)) - 1;
             }
-            if (!base_cached) { c->base_cache_R = -1; c->base_cache_capR = (int)(c->base_cache_cap / (p->N_o * 3 + 1)) - 1; }
             b_states = c->d_base_cache; b_y = c->d_base_cache + (size_t)(c->base_cache_capR + 1) * p->N_o * 3;
-        } else {
-            b_states = sl.take<float>((size_t)(R_base + 1) * p->N_o * 3);
-            b_y = sl.take<float>(R_base + 1);
         }
-        int* b_rep_eff = sl.take<int>(nrep); int* b_start = sl.take<int>(p->B);
-        float* b_eef = sl.take<float>((size_t)5 * p->M);   // parked tool: xz (M,2), delta (M,3)
-        int* b_zero = sl.take<int>(1);
-        if (sl.used > sl.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
+        if (!plan_done) {
         const float far = 1.0e6f;                            // out of every particle's reach; delta 0: it stays there
         int far_bits; memcpy(&far_bits, &far, 4);
         HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b_eef), far_bits, (size_t)2 * p->M, st));
@@ -1178,51 +1370,46 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             }
         }
         // ---- contact plan -> forwards left per candidate, back on the host (the one wait of a prefix-sharing call)
-        const int* d_rep_orig = dev_plan ? pl_repeat : c->d_repeat;
         ContactPlan cp{};
-        cp.base_states = b_states; cp.base_y = b_y; cp.R = R_base; cp.eef_xz = d_eef_xz; cp.eef_delta = d_eef_delta; cp.repeat = d_rep_orig;
+        cp.base_states = b_states; cp.base_y = b_y; cp.R = R_base; cp.R_bound = rep_bound;
+        cp.eef_xz = d_eef_xz; cp.eef_delta = d_eef_delta; cp.repeat = d_rep_orig;
         cp.B = p->B; cp.H = p->H; cp.N_o = p->N_o; cp.M = p->M; cp.thr = p->adj_thresh; cp.rep_eff = b_rep_eff; cp.start = b_start;
         cp.state_seqs = d_state_seqs;
         HIPCHK(c, launch_contact_plan(cp, st));
-        if (c->rep_pin_cap < 2 * nrep) {
-            if (c->h_rep_pin) HIPCHK(c, hipHostFree(c->h_rep_pin));
-            c->h_rep_pin = nullptr; c->rep_pin_cap = 0;
-            HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_rep_pin), (2 * nrep + 64) * 4, hipHostMallocDefault));
-            c->rep_pin_cap = 2 * nrep + 64;
+        HIPCHK(c, hipMemcpyAsync(sl.h_rep_pin, b_rep_eff, nrep * 4, hipMemcpyDeviceToHost, st));
+        if (dev_plan) HIPCHK(c, hipMemcpyAsync(sl.h_rep_pin + nrep, pl_repeat, nrep * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(sl.h_rep_pin + 2 * nrep, d_overflow_flag, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipEventRecord(sl.ev_plan, st));
+        HIPCHK(c, hipEventSynchronize(sl.ev_plan));
         }
-        if (!c->ev_plan) HIPCHK(c, hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
-        HIPCHK(c, hipMemcpyAsync(c->h_rep_pin, b_rep_eff, nrep * 4, hipMemcpyDeviceToHost, st));
-        if (dev_plan) HIPCHK(c, hipMemcpyAsync(c->h_rep_pin + nrep, pl_repeat, nrep * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(c->h_rep_pin + 2 * nrep, d_overflow_flag, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipEventRecord(c->ev_plan, st));
-        HIPCHK(c, hipEventSynchronize(c->ev_plan));
-        if (census && !d_phys_vec && !base_cached) {
-            // keep the base rollout for later calls - unless its graphs overflowed max_nR (that call must raise by itself)
-            const bool clean = c->h_rep_pin[2 * nrep] <= p->max_nR;
+        if (base_in_ctx && !base_cached) {
+            // keep the base rollout for later calls - unless its graphs overflowed max_nR (that call must raise by itself).
+            // (memcmp compares the keys, padding included: both sides are memset + field-wise filled and copied with memcpy; a
+            // spurious mismatch could only cost a re-computation, never a wrong re-use)
+            const bool clean = sl.h_rep_pin[2 * nrep] <= p->max_nR;
             c->base_cache_R = clean ? R_base : -1;
-            c->base_key = base_key_now;
+            memcpy(&c->base_key, &key_now, sizeof key_now);
         }
         if (dev_plan) {
             c->fwd_needed = 0;
-            for (size_t i = 0; i < nrep; ++i) c->fwd_needed += std::min(std::max(0, c->h_rep_pin[nrep + i]), R);
+            for (size_t i = 0; i < nrep; ++i) c->fwd_needed += std::min(std::max(0, sl.h_rep_pin[nrep + i]), R);
             c->d_plan_sums = nullptr;
         }
         c->fwd_executed = base_cached ? 0 : R_base;          // the base rollout's forwards (none when an earlier call's is re-used)
-        rc = host_plan(c->h_rep_pin);                         // launch order and sizes from the forwards that are LEFT
+        rc = host_plan(sl.h_rep_pin);                         // launch order and sizes from the forwards that are LEFT
         if (rc) return rc;
         d_start = b_start; d_base_states = b_states; d_base_y = b_y;
     }
     hipStream_t streams[ag_ctx::kMaxStreams] = {st, st, st, st};
     if (ns > 1) {
-        if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIPCHK(c, hipEventRecord(c->ev_fork, st));            // inputs / memset / repeat upload are ordered before
+        HIPCHK(c, hipEventRecord(sl.ev_fork, st));            // inputs / memset / repeat upload are ordered before
         for (int i = 1; i < ns; ++i) {
-            if (!c->aux_stream[i]) {
-                HIPCHK(c, hipStreamCreateWithFlags(&c->aux_stream[i], hipStreamNonBlocking));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+            if (!sl.aux_stream[i]) {
+                HIPCHK(c, stream_new(c, &sl.aux_stream[i]));
+                HIPCHK(c, event_new(c, &sl.ev_join[i]));
             }
-            streams[i] = c->aux_stream[i];
-            HIPCHK(c, hipStreamWaitEvent(c->aux_stream[i], c->ev_fork, 0));
+            streams[i] = sl.aux_stream[i];
+            HIPCHK(c, hipStreamWaitEvent(sl.aux_stream[i], sl.ev_fork, 0));
         }
     }
 
@@ -1234,7 +1421,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     // below, so that a failure in the middle never leaves work of this call in flight on a stream the caller cannot see.
     auto enqueue_chunks = [&]() -> int {
     bool obj_cls_ready[ag_ctx::kMaxStreams] = {false, false, false, false};   // per workspace, per call
-    bool plan_landed = false;                                // device plan: the chunk maxima are in c->h_plan_max
+    bool plan_landed = false;                                // device plan: the chunk maxima are in sl.h_plan_max
     c->steps_enqueued = 0; c->steps_bound = 0;
     int ci = 0;
     for (int b0 = 0; b0 < p->B; b0 += Bc, ++ci) {
@@ -1255,7 +1442,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         ra.B = nb; ra.B_slots = nb; ra.N_o = p->N_o; ra.M = p->M; ra.H = p->H; ra.y_mode = p->y_mode; ra.b0 = b0;
         ra.grip = p->gripper_offset; ra.grip_on = p->gripper_enable; ra.phys = p->physics_param; ra.phys_vec = d_phys_vec;
         ra.state0 = d_state0; ra.state0_batched = p->y_mode == 1; ra.obj_mask = d_obj_mask;
-        ra.eef_xz = d_eef_xz; ra.eef_delta = d_eef_delta; ra.repeat = loop_dev ? pl_repeat : c->d_repeat; ra.state_seqs = d_state_seqs;
+        ra.eef_xz = d_eef_xz; ra.eef_delta = d_eef_delta; ra.repeat = loop_dev ? pl_repeat : sl.d_repeat; ra.state_seqs = d_state_seqs;
         ra.start = d_start; ra.base_states = d_base_states; ra.base_y = d_base_y;
         EdgeArgs ea{};
         ea.pos = w.r.hist + (size_t)(n_his - 1) * N * 3; ea.pos_bstride = (long)n_his * N * 3;   // the newest frame
@@ -1271,7 +1458,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         }
         w.r.ragged = ragged ? 1 : 0; w.r.clamp = c->dims.motion_clamp;
         if (ragged) {   // the mask does not change during a rollout: one work list per chunk and call, in slot order (H = 1)
-            const int* d_cand0 = sort_on ? c->d_repeat + nrep + b0 : nullptr;
+            const int* d_cand0 = sort_on ? sl.d_repeat + nrep + b0 : nullptr;
             HIPCHK(c, launch_build_rowlist(d_obj_mask, d_cand0, b0, nb, p->N_o, p->M, w.rowlist, w.n_rows, w.r.mask, w.deg, cs));
             HIPCHK(c, hipMemsetAsync(w.row_ptr + (size_t)nb * (N + 1), 0, (size_t)(N + 1) * 4, cs));   // CSR path: no edges
             g.rowlist = w.rowlist; g.n_rows = w.n_rows + nb;
@@ -1282,7 +1469,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             if (!loop_dev) for (int b = 0; b < nb; ++b) max_rep = std::max(max_rep, h_repeat[(size_t)seg[b] * p->H + li]);
             if (max_rep == 0 && !loop_dev) continue;          // nothing of this chunk is stepped in this look-ahead step
             ra.li = li; ra.ai = 0; ra.B = nb; ra.live = nullptr;
-            ra.cand = loop_dev ? pl_cand + (size_t)li * p->B + b0 : sort_on ? c->d_repeat + nrep + (size_t)li * p->B + b0 : nullptr;
+            ra.cand = loop_dev ? pl_cand + (size_t)li * p->B + b0 : sort_on ? sl.d_repeat + nrep + (size_t)li * p->B + b0 : nullptr;
             const int* live_row = loop_dev ? pl_live + ((size_t)ci * p->H + li) * (R + 2) : nullptr;
             const int* rows_row = loop_dev ? pl_rows + ((size_t)ci * p->H + li) * (R + 2) : nullptr;
             // masked variant: the object rows depend on nothing per-candidate either (both validity variants are
@@ -1300,10 +1487,10 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
                 if (loop_dev) {
                     // past this chunk's own maximum no slot is live: stop as soon as the plan's maxima are known (no waiting)
                     if (!plan_landed && ai > 1 && !capturing) {
-                        if (hipEventQuery(c->ev_plan) == hipSuccess) plan_landed = true;
+                        if (hipEventQuery(sl.ev_plan) == hipSuccess) plan_landed = true;
                         else (void)hipGetLastError();       // "not ready" must not be taken for a failed launch by the next check
                     }
-                    if (plan_landed && ai > c->h_plan_max[(size_t)ci * p->H + li]) break;
+                    if (plan_landed && ai > sl.h_plan_max[(size_t)ci * p->H + li]) break;
                 }
                 ++c->steps_enqueued;
                 if (loop_dev) {   // grids cover the whole chunk; the kernels read how many slots are live from the plan's table
@@ -1319,7 +1506,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
                 ea.send_pk = share_step ? w.send_pk : nullptr; g.send_pk = ea.send_pk;
                 if (share_step) {
                     ea.base_send = base_send; ea.base_deg = base_deg; ea.base_stride = kb; ea.share_No = p->N_o;
-                    ea.share_stats = c->d_share_stats; g.C_share = C_share; g.share_kb = kb;
+                    ea.share_stats = sl.d_share_stats; g.C_share = C_share; g.share_kb = kb;
                     ea.share_start = d_start; ea.share_cand = ra.cand; ea.share_b0 = b0;
                 }
                 HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));
@@ -1336,16 +1523,13 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     const int rc_loop = enqueue_chunks();
     int rc_join = AG_OK;
     for (int i = 1; i < ns; ++i) {                           // join on EVERY exit once the fork has happened
-        hipError_t e = hipEventRecord(c->ev_join[i], c->aux_stream[i]);
-        if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_join[i], 0);
+        hipError_t e = hipEventRecord(sl.ev_join[i], sl.aux_stream[i]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, sl.ev_join[i], 0);
         if (e != hipSuccess && rc_join == AG_OK && rc_loop == AG_OK)
             rc_join = fail(c, AG_ERR_HIP, "joining stream %d failed: %s", i, hipGetErrorString(e));
     }
     c->prof_stream = st;
-    if (!capturing) {                                        // (a captured event could not be waited for outside its graph)
-        if (!c->ev_done && hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) c->ev_done = nullptr;
-        if (c->ev_done && hipEventRecord(c->ev_done, st) == hipSuccess) { c->have_done = true; c->last_stream = st; }
-    }
+    slot_release(&sl, st, capturing);                        // (a captured event could not be waited for outside its graph)
     return rc_loop ? rc_loop : rc_join;
 }
 }  // namespace
@@ -1378,11 +1562,15 @@ int ag_rollout(ag_ctx* c, void* stream, const ag_rollout_params* p, const float*
     if (!c) return AG_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIPCHK(c, hipMemsetAsync(c->d_overflow, 0, 4, st));
-    int rc = ag_rollout_async(c, stream, p, d_state0, d_obj_mask, d_eef_xz, d_eef_delta, h_repeat, d_phys_vec, d_state_seqs, c->d_overflow);
+    CallSlot* sl = nullptr;
+    int rc = slot_acquire(c, st, false, &sl);                 // (the call below finds the same slot: same stream)
+    if (rc) return rc;
+    int* d_word = sl->d_words;
+    HIPCHK(c, hipMemsetAsync(d_word, 0, 4, st));
+    rc = ag_rollout_async(c, stream, p, d_state0, d_obj_mask, d_eef_xz, d_eef_delta, h_repeat, d_phys_vec, d_state_seqs, d_word);
     if (rc) return rc;
     int seen = 0;
-    HIPCHK(c, hipMemcpyAsync(&seen, c->d_overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&seen, d_word, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     if (seen > p->max_nR) return fail(c, AG_ERR_MAX_NR, "Exceeds max dims: a graph had %d edges, max_nR=%d", seen, p->max_nR);
     return AG_OK;

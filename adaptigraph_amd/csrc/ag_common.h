@@ -92,6 +92,10 @@ struct Options {
                               //                     not touched the object yet follow ONE tool-free base rollout (-1: batches of >= 64
                               //                     candidates and >= 32768 rows, 0 never, 1 whenever possible).  Waits once per call
                               //                     for the contact plan (the GPU is busy with the base rollout meanwhile)
+    int stream_min_rows = 65536;  // [AG_STREAM_MIN_ROWS] batches below this many rows (candidates x particles) stay on the caller's stream
+    int pipeline_fork = 0;    // [AG_PIPELINE_FORK]  1: a call forks onto in-library streams even while a call issued on ANOTHER caller
+                              //                     stream is still running (0: such a call stays on its stream - the caller is
+                              //                     already spreading independent calls over streams, adaptigraph_amd/planner.py)
     int share_first = -1;     // [AG_SHARE_FIRST]    first forward of a dynamics() call: the relation encoder runs ONCE over the
                               //                     object-object edges of the start state's tool-free graph and every candidate reads
                               //                     those C rows (-1: batches of 8 candidates or more, 0 never, 1 whenever possible)
@@ -271,6 +275,10 @@ struct ContactPlan {
     // to run, count[2] = max repeat of look-ahead step 0; the tool height of the start state is formed here (min object y +
     // gripper offset, forward_dynamics.py:40,80-81)
     int* count; float grip; int grip_on;
+    // device-planned calls (ag_rollout_actions): the caller's bound of action_repeat.  A candidate beyond it is treated as the
+    // plain device-planned path treats it - never captured (its rows stay zero; the shim marks them NaN) - and later look-ahead
+    // steps are stepped at most R_bound times.  Host-planned calls: INT_MAX.
+    int R_bound;
 };
 // count += number of 32-bit words in which a and b differ (bitwise)
 hipError_t launch_count_diff(const float* a, const float* b, long n, int* count, hipStream_t st);

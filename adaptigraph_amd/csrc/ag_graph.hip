@@ -485,7 +485,11 @@ __global__ __launch_bounds__(CT) void k_contact_plan(ContactPlan p) {
         if (tid == 0) { if (hit) atomicAdd(p.count, 1); atomicAdd(p.count + 1, 1); atomicMax(p.count + 2, rep); }
         return;
     }
-    for (int li = 1 + tid; li < p.H; li += CT) p.rep_eff[(long)b * p.H + li] = p.repeat[(long)b * p.H + li];
+    for (int li = 1 + tid; li < p.H; li += CT) p.rep_eff[(long)b * p.H + li] = min(p.repeat[(long)b * p.H + li], p.R_bound);
+    if (p.repeat[(long)b * p.H] > p.R_bound) {               // beyond the caller's bound: not stepped, not captured (rows stay zero)
+        if (tid == 0) { p.rep_eff[(long)b * p.H] = 0; p.start[b] = 0; }
+        return;
+    }
     const int rep = min(max(p.repeat[(long)b * p.H], 0), p.R);
     const float thr2 = __fmul_rn(p.thr, p.thr);
     float tx[8], tz[8], dx[8], dz[8];

@@ -130,8 +130,10 @@ def mpc_iteration(state_cur, act_seq, model_rollout_fn, evaluate_traj_fn, action
             reward_seqs = all_gather_costs(reward_seqs.contiguous(), act_seqs.shape[0], pg)
         nominal = optimize_action_mppi(act_seqs, reward_seqs, reward_weight, action_lower_lim, action_upper_lim, push_length)
         top = torch.argmax(reward_seqs)
-        if best_reward is None or bool(reward_seqs[top] > best_reward):       # planner.py:254-260
-            best_act_seq, best_reward = act_seqs[top], reward_seqs[top]
+        sel = top.reshape(1)                                                  # (index_select: no read-back of `top`)
+        top_reward = torch.index_select(reward_seqs, 0, sel)[0]
+        if best_reward is None or bool(top_reward > best_reward):             # planner.py:254-260
+            best_act_seq, best_reward = torch.index_select(act_seqs, 0, sel)[0], top_reward
             if reuse_best_rollout and world == 1:
                 n = act_seqs.shape[0]
                 best_rows = {k: (torch.index_select(v, 0, top.reshape(1)) if isinstance(v, torch.Tensor) and v.dim() > 0 and

@@ -18,6 +18,17 @@ arithmetic of the hot path.  What is new:
   samples (same seed), rolls out and evaluates its chunks, the chunk winners (n_chunk x n_look_ahead x action_dim
   floats) are all-gathered, and every rank re-evaluates the winners itself - no batch-global reduction crosses ranks.
 * `planner_type` 'GD' raises NotImplementedError: it differentiates through the rollout and the engine has no backward.
+* The reference's own loop - 40 x `trajectory_optimization`, then `merge_res` - is served as it stands (r05): when
+  `model_rollout_fn` is the engine's `dynamics` behind a `functools.partial` (what plan.py:190 builds), consecutive calls on
+  the same `state_cur` / `act_seq` tensors are independent of each other, and the class deals them to `pipeline_chunks` (default
+  4) side streams: each call's sampling, rollout, evaluation and update are enqueued on one of them without waiting for the GPU
+  (the rollout's "Exceeds max dims" flag comes back through pinned memory), the caller's stream is made to wait (on the GPU) for
+  the call's end before the result is handed back - so results are used in stream order as always - and the next call starts on
+  another stream while this one still runs.  Same samples (the generator advances on the host, in call order), same per-candidate
+  results (a rollout does not depend on its batch, stream or neighbours, bit for bit), so the same winner.  What changes:
+  "Exceeds max dims" of call i surfaces at a later call or at `merge_res` - where the reference's loop first reads a result
+  back (planner.py:312-314) - instead of inside call i; `pipeline_chunks: 0` restores the strict behaviour.  Also (r05) the
+  winner's rollout is taken out of its batch (`reuse_best_rollout`) by default when the rollout is the engine's.
 
 The progress lines the reference prints on every call go to stdout only with `verbose`.
 """
@@ -46,6 +57,31 @@ def farthest_points(points, num, init_idx=-1):
         chosen.append(nxt)
         nearest = np.minimum(nearest, np.linalg.norm(pts - pts[nxt], axis=1))
     return pts[chosen]
+
+
+def _engine_rollout(fn):
+    """`fn` if it is the engine's dynamics() bound with keywords only, as plan.py:190 binds it - the callable whose calls may
+    be issued without waiting (`_sync=False`) and whose per-candidate results do not depend on the batch - else None."""
+    import functools
+    from .forward_dynamics import dynamics
+    from .model import DynamicsPredictor
+    if not (isinstance(fn, functools.partial) and fn.func is dynamics and not fn.args):
+        return None
+    kw = fn.keywords or {}
+    if "_sync" in kw or "_overflow_flag" in kw or not isinstance(kw.get("model"), DynamicsPredictor) or "ppm_optimizer" not in kw:
+        return None
+    return fn
+
+
+def _tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors(v)
 
 
 def _require_rank_local(fn, what):
@@ -111,7 +147,18 @@ class Planner(object):
         # batch it was sampled in instead of being computed again with a batch of one (planner.py:268-271).  Exact on this
         # engine - a candidate's rollout does not depend on its batch, bit for bit - and NOT in general (a BLAS-backed
         # rollout may round differently at another batch size), so it is the caller's statement about model_rollout_fn.
-        self.reuse_best_rollout = bool(config.get("reuse_best_rollout", False))
+        # r05: default ON when model_rollout_fn is the engine's own dynamics() (then the statement is the engine's, tested by
+        # test_dynamics_chunking_is_bit_invariant), OFF for any other callable.
+        self._eng_rollout = _engine_rollout(self.model_rollout)
+        self.reuse_best_rollout = bool(config.get("reuse_best_rollout", self._eng_rollout is not None))
+        # Side streams the independent calls of the caller's chunk loop are dealt to (module docstring); 0 / 1: every call on
+        # the caller's stream, waiting for its rollout's flags (the strict per-call error behaviour).
+        self.pipeline_chunks = int(config.get("pipeline_chunks", 4 if self._eng_rollout is not None else 0))
+        self._side = None            # (device, [streams])
+        self._pipe_in = None         # (state_cur, act_seq, (versions, caller stream), entry event): inputs of the running series
+        self._pipe_i = 0
+        self._call_flags = None      # flag tensors of the rollouts of the call being enqueued
+        self._pending = []           # (pinned flag copy, done event) of calls whose flags have not been looked at
         self.chunk_id = 0
         self.total_chunks = 1
 
@@ -168,12 +215,95 @@ class Planner(object):
         assert type(state_cur) == torch.Tensor and type(act_seq) == torch.Tensor
         assert act_seq.shape == (self.n_look_ahead, self.action_dim)
         if self.planner_type == "MPPI":
+            if self._can_pipeline(state_cur):
+                return self._pipelined(state_cur, act_seq)
+            self.check_pending(block=True)                   # (a strict call: nothing of earlier calls stays unreported)
             return self.trajectory_optimization_mppi(state_cur, act_seq)
         if self.planner_type == "GD":
             return self.trajectory_optimization_gd(state_cur, act_seq)
         if self.planner_type == "MPPI_GD":
             raise NotImplementedError
         raise ValueError("unknown planner type: %s" % self.planner_type)
+
+    # ---------------------------------------------------------------- independent calls dealt to side streams (module docstring)
+    def _can_pipeline(self, state_cur):
+        # (not with a process group: an evaluation that issues collectives keeps its issue order on the caller's stream)
+        return (self.pipeline_chunks >= 2 and self._eng_rollout is not None and not self.verbose and state_cur.is_cuda
+                and self.group is None and not torch.cuda.is_current_stream_capturing())
+
+    def _limits_of_rollout(self):
+        from .forward_dynamics import _repeat_bound
+        task = self._eng_rollout.keywords["ppm_optimizer"].task_config
+        return int(task["max_nR"]), _repeat_bound(task)
+
+    def _rollout(self, state_cur, act_seqs):
+        """model_rollout_fn; inside a pipelined call the engine's dynamics() is told not to wait for its flags"""
+        if self._call_flags is None:
+            return self.model_rollout(state_cur, act_seqs)
+        flags = torch.zeros(2, dtype=torch.int32, device=state_cur.device)
+        self._call_flags.append(flags)
+        return self._eng_rollout(state_cur, act_seqs, _sync=False, _overflow_flag=flags)
+
+    def check_pending(self, block=True):
+        """Look at the flags of the pipelined calls that have finished (block: wait for all of them): raises what their
+        dynamics() would have raised.  Called by every trajectory_optimization (non-blocking) and by merge_res (blocking)."""
+        if not self._pending:
+            return
+        max_nR, bound = self._limits_of_rollout()
+        keep = []
+        err = None
+        for host, done in self._pending:
+            if block:
+                done.synchronize()
+            elif not done.query():
+                keep.append((host, done))
+                continue
+            for seen_nR, seen_rep in host.tolist():           # pinned host memory, written before `done`: no device access
+                if seen_nR > max_nR:
+                    err = Exception("Exceeds max dims")        # utils.py:63-65
+                elif bound is not None and seen_rep > bound and err is None:
+                    err = ValueError(f"an action's repeat count {seen_rep} exceeds the task config's action_upper_lim[3] = {bound}: "
+                                     "a pipelined planner call cannot fall back to the host decode (planner config "
+                                     "'pipeline_chunks': 0 restores the per-call behaviour)")
+        self._pending = keep
+        if err is not None:
+            self._pending = []
+            raise err
+
+    def _pipelined(self, state_cur, act_seq):
+        dev = state_cur.device
+        cur = torch.cuda.current_stream(dev)
+        self.check_pending(block=False)
+        # Are these the inputs of the previous call, untouched?  (same tensor objects, same version counters, same caller
+        # stream.)  Then they were ready where that series started and this call need not queue up behind the previous one.
+        tag = (state_cur._version, act_seq._version, cur.cuda_stream)
+        pin = self._pipe_in
+        if pin is None or pin[0] is not state_cur or pin[1] is not act_seq or pin[2] != tag:
+            entry = torch.cuda.Event()
+            entry.record(cur)
+            self._pipe_in = pin = (state_cur, act_seq, tag, entry)
+        if self._side is None or self._side[0] != dev or len(self._side[1]) != self.pipeline_chunks:
+            self._side = (dev, [torch.cuda.Stream(dev) for _ in range(self.pipeline_chunks)])
+        side = self._side[1][self._pipe_i % len(self._side[1])]
+        self._pipe_i += 1
+        side.wait_event(pin[3])
+        self._call_flags = []
+        try:
+            with torch.cuda.stream(side):
+                res = self.trajectory_optimization_mppi(state_cur, act_seq)
+                flags = self._call_flags
+                host = torch.empty((len(flags), 2), dtype=torch.int32, pin_memory=True)
+                if flags:
+                    host.copy_(torch.stack(flags), non_blocking=True)
+        finally:
+            self._call_flags = None
+        done = torch.cuda.Event()
+        done.record(side)
+        cur.wait_event(done)                                 # the caller uses the result in stream order, as always
+        for t in _tensors(res):
+            t.record_stream(cur)
+        self._pending.append((host, done))
+        return res
 
     def _evaluate(self, model_out, act_seqs, state_cur):
         return self.evaluate_traj(model_out["state_seqs"], act_seqs, state_cur=state_cur,
@@ -191,14 +321,17 @@ class Planner(object):
             act_seqs = self.sample_action_sequences(act_seq, iter_index=i)
             assert type(act_seqs) == torch.Tensor
             assert act_seqs.shape == (self.n_sample, self.n_look_ahead, self.action_dim)
-            model_out = self.model_rollout(state_cur, act_seqs)
+            model_out = self._rollout(state_cur, act_seqs)
             assert type(model_out["state_seqs"]) == torch.Tensor
             eval_out = self._evaluate(model_out, act_seqs, state_cur)
             reward_seqs = eval_out["reward_seqs"]
             act_seq = self.optimize_action(act_seqs, reward_seqs)
             top = torch.argmax(reward_seqs)
             if i == 0 or reward_seqs[top] > best_reward:
-                best_act_seq, best_reward = act_seqs[top], reward_seqs[top]
+                # (index_select, not act_seqs[top]: indexing with a 0-d GPU tensor makes torch read it back - a wait for the
+                # whole rollout and evaluation that the reference's own loop pays, planner.py:256-257; same values)
+                sel = top.reshape(1)
+                best_act_seq, best_reward = torch.index_select(act_seqs, 0, sel)[0], torch.index_select(reward_seqs, 0, sel)[0]
                 if self.reuse_best_rollout:
                     best_rows = self._pick(model_out, top, act_seqs.shape[0])
             if self.verbose:
@@ -207,7 +340,7 @@ class Planner(object):
         act_seq = best_act_seq
         best_model_out = best_eval_out = None
         if self.rollout_best:
-            best_model_out = best_rows if best_rows is not None else self.model_rollout(state_cur, act_seq.unsqueeze(0))
+            best_model_out = best_rows if best_rows is not None else self._rollout(state_cur, act_seq.unsqueeze(0))
             best_eval_out = self.evaluate_traj(best_model_out["state_seqs"], act_seq.unsqueeze(0), state_cur=state_cur)
         return {"act_seq": act_seq,
                 "model_outputs": model_outputs if self.verbose else None,
@@ -224,7 +357,9 @@ class Planner(object):
     def merge_res(self, res_list):
         """planner.py:311-323: the chunk whose winner scores best in its own batch-of-one re-evaluation."""
         assert not self.verbose and self.rollout_best
-        scores = [res["best_eval_output"]["reward_seqs"].mean().item() for res in res_list]
+        self.check_pending(block=True)                        # flags of the pipelined calls: here the reference's loop syncs too
+        # (one read-back for all chunks; .mean() of the (1,) reward and the Python float are the reference's, planner.py:312-314)
+        scores = torch.stack([res["best_eval_output"]["reward_seqs"].mean() for res in res_list]).tolist()
         win = res_list[int(np.argmax(scores))]
         return {"act_seq": win["act_seq"], "model_outputs": None, "eval_outputs": None,
                 "best_model_output": win["best_model_output"], "best_eval_output": win["best_eval_output"]}
@@ -290,7 +425,7 @@ class Planner(object):
                 reward_seqs = self._evaluate(part, samples[c_lo + j], state_cur)["reward_seqs"]
                 assert reward_seqs.shape == (S,)
                 top = torch.argmax(reward_seqs)
-                winners[j] = samples[c_lo + j][top]
+                winners[j] = torch.index_select(samples[c_lo + j], 0, top.reshape(1))[0]      # (no read-back of `top`)
                 if reuse:
                     picked.append(self._pick(part, top, S))
         if world > 1:

@@ -19,12 +19,27 @@
  *     comment says so.
  *   - The caller owns every input/output buffer.  The library owns only its
  *     ctx workspace (grown monotonically, freed by ag_ctx_destroy).
- *   - One ctx per (process, device); a ctx is not re-entrant (one host thread at a time).  The launch plan, the repeat table
- *     and the workspace are per-ctx state that the kernels of a call read until that call's work has drained: a rollout call
- *     (ag_rollout, ag_rollout_async, ag_rollout_actions) issued on ANOTHER stream than the previous one first makes its stream wait
- *     for the previous call's end (an event; calls on one stream are ordered by the stream).  Early returns before any
- *     work was enqueued (argument errors) record nothing.  A call that is being captured into a hipGraph neither waits nor records:
- *     the caller serialises around a capture.
+ *   - One ctx per (process, device); a ctx is not re-entrant (one host thread at a time).  Calls on ONE stream are ordered by
+ *     the stream.  Calls issued on DIFFERENT streams run side by side: the launch plan, the repeat table, the workspace and the
+ *     pinned read-back buffers of a call belong to a per-stream "call slot" (up to 4 per ctx; r05).  A fifth stream takes over the
+ *     least recently used slot and first waits (GPU side, an event) for that slot's last call.  That is what lets a caller deal
+ *     the 40 independent dynamics() calls of the planner's chunk loop (plan.py:241-247) to a few streams
+ *     (adaptigraph_amd/planner.py).  Early returns before any work was enqueued (argument errors) record nothing.  A call that is
+ *     being captured into a hipGraph neither waits nor records: the caller serialises around a capture.
+ *   - WHICH ENTRY POINTS BLOCK THE HOST, and when (everything else only enqueues):
+ *       ag_ctx_load_weights, ag_ctx_set_precision     always (host repack + copies)
+ *       ag_forward, ag_rollout                        once, at the end: they return the overflow verdict (AG_ERR_MAX_NR)
+ *       ag_ctx_rollout_counts (after a device-planned call without prefix sharing), ag_ctx_share_counts   wait for the device
+ *       ag_rollout_async, ag_rollout_actions          only when the contact-free prefix is in play (option "share_prefix";
+ *           y_mode 0, by default batches of >= 64 candidates and >= 32768 rows), and then for SMALL plan kernels at the start
+ *           of the call, never for the rollout: (a) a base rollout of this start state is kept in the ctx: ONE wait for census +
+ *           state compare + contact plan, enqueued together; (b) the last census of this shape said "not worth it" (e.g. every
+ *           push starts on the object): NO wait - a census goes out that a later call reads; (c) otherwise: one wait for the
+ *           census, and if it keeps the sharing a second one for the contact plan, the GPU running the base rollout meanwhile.
+ *           An event wait on the caller's stream: it also covers whatever the caller enqueued on that stream before the call.
+ *           "share_prefix" 0 keeps both purely asynchronous.
+ *     Device memory, pinned memory, events and streams are created when a call slot first sees a shape and kept: a repeated call
+ *     of the same shape on the same stream allocates nothing (ag_ctx_alloc_counts; hipMalloc / hipFree are device-wide syncs).
  *   - No float atomics anywhere: results are bit-reproducible and independent
  *     of how candidates are chunked or sharded across GPUs.
  */
@@ -45,7 +60,7 @@ extern "C" {
 #define AG_ERR_UNSUPPORTED -4  /* configuration outside what the kernels implement                            */
 #define AG_ERR_NO_WEIGHTS -5   /* forward/rollout before ag_ctx_load_weights                                   */
 
-#define AG_ABI_VERSION 6
+#define AG_ABI_VERSION 7
 #define AG_NUM_WEIGHT_TENSORS 22
 
 typedef struct ag_ctx ag_ctx;
@@ -145,7 +160,12 @@ int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
  *                                         (a census: one more tiny kernel and wait) (default), 0 never, 1 whenever possible.  The call
  *                                         WAITS once for the contact plan (the GPU is running the base rollout meanwhile), so
  *                                         ag_rollout_async / ag_rollout_actions are then not purely asynchronous
- * Unknown names and values outside an option's range return AG_ERR_INVALID (ranges: streams 0..4, chunk 0..2^20, latency -1..1,
+ *   "stream_min_rows" [AG_STREAM_MIN_ROWS] batches below this many rows (candidates x particles) stay on the caller's stream
+ *                                         (default 65536: small batches are dispatch-bound, a second stream only doubles the launches)
+ *   "pipeline_fork"  [AG_PIPELINE_FORK]   0 (default): a call that starts while a call issued on ANOTHER caller stream is still running
+ *                                         does not fork onto in-library streams (the caller is already spreading independent calls
+ *                                         over streams); 1: it forks as usual
+ * Unknown names and values outside an option's range return AG_ERR_INVALID (ranges: stream_min_rows 0..INT32_MAX, pipeline_fork 0..1, streams 0..4, chunk 0..2^20, latency -1..1,
  * the 0/1 switches 0..1, edge_wgs 1..65536, edge_block_min -1..INT32_MAX, enc_persist 0..2^20, stagger_us 0..1000,
  * device_decode -1..1, share_first -1..1, share_prefix -1..1). */
 int ag_ctx_set_option(ag_ctx* ctx, const char* name, int32_t value);
@@ -166,6 +186,11 @@ int ag_ctx_rollout_counts(ag_ctx* ctx, int64_t* out_executed, int64_t* out_neede
  * to the host asynchronously (pinned memory + event, never waited for); once they have landed the enqueue loop stops a
  * look-ahead step at the chunk's own maximum, so out2[0] <= out2[1].  Host bookkeeping only: no device access. */
 int ag_ctx_launch_counts(ag_ctx* ctx, int64_t* out2);
+
+/* out[0] = number of device / pinned allocations and frees, event and stream creations this context has made so far.  A
+ * steady-state call - same shape, same stream as an earlier one - makes none (tests/test_gpu_share_prefix.py).  Host
+ * bookkeeping only. */
+int ag_ctx_alloc_counts(ag_ctx* ctx, int64_t* out1);
 
 /* Shared first forward ("share_first") of the LAST ag_rollout / ag_rollout_async / ag_rollout_actions call on this context:
  * out3[0] = edges the once-per-call base encode ran over (0 when the call did not share), out3[1] = edge slots of all
@@ -246,10 +271,8 @@ int ag_rollout(ag_ctx* ctx, void* stream, const ag_rollout_params* p, const floa
 
 /* Same, but does not wait for the rollout: enqueue only.  *d_overflow_flag (int32, device, caller-zeroed) receives the max
  * edge count seen if it exceeded max_nR.  Used by bench.py to time the pure device path.  One exception: a call that shares the
- * contact-free prefix (option "share_prefix": y_mode 0, by default batches of >= 64 candidates and >= 32768 rows) waits for the
- * small plan kernels at its start - once for the census of the first forward (automatic mode), once for the contact plan, the
- * GPU running the base rollout meanwhile - before it enqueues the candidates' launches; "share_prefix" 0 keeps the call purely
- * asynchronous. */
+ * contact-free prefix (option "share_prefix") waits for small plan kernels at its start, never for the rollout - when and how
+ * often is stated once, at the top of this header ("WHICH ENTRY POINTS BLOCK THE HOST"). */
 int ag_rollout_async(ag_ctx* ctx, void* stream, const ag_rollout_params* p, const float* d_state0,
                      const uint8_t* d_obj_mask, const float* d_eef_xz, const float* d_eef_delta,
                      const int32_t* h_repeat, const float* d_phys_vec, float* d_state_seqs,

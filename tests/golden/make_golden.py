@@ -433,7 +433,7 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5", "--planner", "--fullsize", "--fullsize-more", "--nhis5-rollout"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5", "--planner", "--fullsize", "--fullsize-more", "--fullsize-r05", "--nhis5-rollout"} & set(sys.argv)):
     main()
 
 # dynamics_masked for the other two materials: gripper offset + connect_tools_all (cloth) and the 5-point pusher
@@ -1056,3 +1056,90 @@ def gen_nhis5_rollout(name):
 
 if __name__ == "__main__" and "--nhis5-rollout" in sys.argv:
     gen_nhis5_rollout("dyn_softbody_nhis5")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# r05: the reference's own outputs for EVERY candidate bench.py's parity_check looks at (64 of the timed 1024-candidate cloth
+# batch), so that the driver-run bench line compares the GPU with the reference on all of them and no flip is left to a
+# heuristic; and three more candidates of tools/bench_configs.py's granular batch (BASELINE configs[2]) with per-forward
+# records.  The compact file stores state_seqs only (48.6 KB per candidate) + SHA-256 digests of the inputs it was made from
+# (start state, every weight tensor, task scalars) + the raw actions of its candidates + the REFERENCE's own smallest
+# edge-selection margin per (candidate, look-ahead step), computed from the positions the reference's forwards saw.
+def _sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def gen_fullsize_seqs(name, per_run=4):
+    refs = import_reference()
+    DynamicsPredictor, _, dynamics, _ = refs
+    root = os.path.dirname(os.path.dirname(OUT))
+    sys.path.insert(0, root)
+    import bench as BN
+    from oracle import adaptigraph_oracle as O           # selection_margin only (test infrastructure, like this script)
+    W = BN.random_weights(0)
+    rng = np.random.default_rng(0)
+    cloud = BN.cloth_cloud(45, rng)
+    actions = BN.make_actions(1024, 2, 10, cloud, rng)
+    ids = sorted(set(BN.parity_picks(1024, 64)) | {0, 49, 487, 926, 1023})
+    dyn, task = load_cfg("cloth")
+    task = dict(task)
+    task.update({"max_nR": int(1.2 * 6 * (cloud.shape[0] + 1)) + 64})
+    assert BN.make_task(task["max_nR"])["pusher_points"] == task["pusher_points"]
+    model = make_model(DynamicsPredictor, dyn, 0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()})
+    ppm = make_ppm(task, "cloth")
+    N_o = cloud.shape[0]
+    N = N_o + task["eef_num"]
+    mask1 = np.ones(N, bool)
+    tool1 = np.zeros(N, bool)
+    tool1[N_o:] = True
+    seqs = np.zeros((len(ids), 2, N_o, 3), np.float32)
+    margin = np.zeros((len(ids), 2), np.float64)
+    t0 = time.time()
+    for k in range(0, len(ids), per_run):
+        sub = ids[k:k + per_run]
+        rec = Recorder(model)
+        np.random.seed(0)
+        out = quiet(dynamics, torch.from_numpy(cloud), torch.from_numpy(actions[sub]), model, torch.device("cpu"), ppm)
+        model.forward = rec._orig
+        seqs[k:k + len(sub)] = out["state_seqs"].numpy()
+        F = len(rec.steps)
+        assert F == 20
+        for j in range(len(sub)):
+            per = [O.selection_margin(st["state_last"][j], task["adj_thresh"], mask1, tool1, task["topk"]) for st in rec.steps]
+            margin[k + j] = [min(per[:10]), min(per[10:])]
+        print(f"  {name}: {k + len(sub)}/{len(ids)} candidates, {time.time() - t0:.0f} s", flush=True)
+    store = {"cand_ids": np.asarray(ids, np.int32), "action": actions[ids], "state_seqs": seqs, "reference_margin": margin,
+             "pstep": np.int32(dyn["model_config"]["pstep"]), "sha_state0": _sha(cloud),
+             "task_json": np.frombuffer(json.dumps(task_scalars(task)).encode(), dtype=np.uint8),
+             "reference_seconds": np.float64(time.time() - t0), "per_run": np.int32(per_run)}
+    for kk, v in W.items():
+        store["sha_w::" + kk] = _sha(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **store)
+    size = os.path.getsize(path) / 1e6
+    print(f"{name}: {len(ids)} candidates -> {size:.2f} MB")
+    assert size < 4.0, size
+
+
+def gen_fullsize_granular_more():
+    refs = import_reference()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import bench as BN
+    W = BN.random_weights(0)
+    rng = np.random.default_rng(0)
+    g = (np.arange(32) - 31 / 2.0) * 0.12
+    xx, zz = np.meshgrid(g, g, indexing="ij")
+    p = np.stack([xx.ravel() - 2.0, np.zeros(1024), zz.ravel() + 1.0], 1)
+    gcloud = (p + rng.normal(0, 0.02, p.shape)).astype(np.float32)
+    gact = BN.make_actions(256, 2, 10, gcloud, rng)
+    for name, ids in (("full_granular_b", [85, 170]), ("full_granular_c", [255, 128])):
+        gen_fullsize(name, "granular", gcloud, gact[ids], W, {"max_nR": int(1.2 * 25 * 1029) + 64}, refs, ids)
+
+
+if __name__ == "__main__" and "--fullsize-r05" in sys.argv:
+    if "granular" in sys.argv or "all" in sys.argv:
+        gen_fullsize_granular_more()
+    if "cloth" in sys.argv or "all" in sys.argv:
+        gen_fullsize_seqs("full_cloth_seqs")

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == sorted(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ag_abi_version() == 6
+    assert lib.ag_abi_version() == 7
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = sorted(set(re.findall(r" T (ag_[a-z_]+)$", out, flags=re.M)))
     assert exported == declared, (exported, declared)

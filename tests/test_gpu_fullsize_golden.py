@@ -45,7 +45,8 @@ def O():
 # tie - the rope's smallest selection margin is 1.9e-8), and 0 only for full_granular, where the REFERENCE itself parts
 # from the oracle at forward 18 at a 1e-7 near-tie and the GPU follows the oracle's side
 @pytest.mark.parametrize("name,material,min_clean", [("full_cloth_a", "cloth", 2), ("full_cloth_flip", "cloth", 2),
-                                                     ("full_granular", "granular", 0), ("full_rope", "rope", 3),
+                                                     ("full_granular", "granular", 0), ("full_granular_b", "granular", 0),
+                                                     ("full_granular_c", "granular", 0), ("full_rope", "rope", 3),
                                                      ("full_masked_cloth", "cloth", 2)])
 def test_rollout_vs_reference_at_full_size(ag, O, dev, name, material, min_clean):
     g = load_golden(name)

@@ -2,7 +2,7 @@
 n_sample 20000 evaluated as 40 chunks of n_sample_chunk 500, n_look_ahead 1, n_update_iter 1, push length drawn from the
 yaml's action limits (rope: U[5,15) -> action_repeat 5..14; granular / cloth: U[2,10) -> 2..9), max_nobj 200 object
 particles.  Times one planner call (= one outer MPC iteration's "get action" block, plan.py:241-247):
-  loop     the reference's 40-iteration host loop of Planner.trajectory_optimization + merge_res
+  loop     the reference's 40-iteration host loop of Planner.trajectory_optimization + merge_res (plus variants, see main)
   chunked  Planner.trajectory_optimization_chunked (one rollout call for all 20000 candidates, one for the 40 winners)
 each with the repeat-aware launch order on (default) and off (option repeat_sort 0: every candidate of a launch chunk is
 stepped to the chunk's maximum repeat, as the reference steps the batch).  Prints one JSON object per (material, mode).
@@ -79,7 +79,7 @@ def main():
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--materials", default="rope,granular,cloth")
-    ap.add_argument("--modes", default="loop,chunked,loop_reuse,chunked_reuse")
+    ap.add_argument("--modes", default="loop,chunked,loop_r04,loop_nopipe,loop_reroll,chunked_reroll")
     ap.add_argument("--sorts", default="1,0")
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
@@ -90,23 +90,28 @@ def main():
         eng = m.engine(dev)
         torch.manual_seed(0)
         act_seq = torch.rand((1, 4), device=dev) * (hi - lo) + lo
-        def with_reuse(fn):
+        def variant(fn, pipeline, reuse):
             def run():
-                planner.reuse_best_rollout = True
+                old = planner.pipeline_chunks, planner.reuse_best_rollout
+                planner.pipeline_chunks, planner.reuse_best_rollout = pipeline, reuse
                 try:
                     return fn()
                 finally:
-                    planner.reuse_best_rollout = False
+                    planner.pipeline_chunks, planner.reuse_best_rollout = old
             return run
         loop_fn = lambda: loop_call(planner, s0, act_seq, n_chunk)
         chunked_fn = lambda: planner.trajectory_optimization_chunked(s0, act_seq, n_chunk)
-        # *_reuse: config['reuse_best_rollout'] - the winners' rollouts are sliced out of their batches (exact on this engine)
-        for mode, fn in (("loop", loop_fn), ("chunked", chunked_fn), ("loop_reuse", with_reuse(loop_fn)),
-                         ("chunked_reuse", with_reuse(chunked_fn))):
+        # loop / chunked: the class as a drop-in gets it (r05: independent calls dealt to 4 streams, winners' rollouts taken out of
+        # their batches).  loop_r04: one stream, every call waits for its flags, winners re-rolled with a batch of one (the r04
+        # behaviour).  loop_nopipe / loop_reroll: one of the two r05 changes each.  chunked_reroll: winners re-rolled (one call).
+        for mode, fn in (("loop", variant(loop_fn, 4, True)), ("chunked", variant(chunked_fn, 4, True)),
+                         ("loop_r04", variant(loop_fn, 0, False)), ("loop_nopipe", variant(loop_fn, 0, True)),
+                         ("loop_reroll", variant(loop_fn, 4, False)), ("loop_2streams", variant(loop_fn, 2, True)),
+                         ("loop_3streams", variant(loop_fn, 3, True)), ("chunked_reroll", variant(chunked_fn, 4, False))):
             if mode not in args.modes.split(","):
                 continue
             for sort in [int(x) for x in args.sorts.split(",")]:
-                if mode.endswith("_reuse") and sort == 0:
+                if mode not in ("loop", "chunked") and sort == 0:
                     continue
                 with eng.options(repeat_sort=sort):
                     torch.manual_seed(1)
@@ -135,7 +140,9 @@ def main():
                                             f"{int(np.ceil(LIMITS[mat][1][3])) - 1}",
                                   "mode": mode, "repeat_sort": sort, "ms_per_planner_call": dt * 1e3,
                                   "candidate_forwards_executed": int(ex), "candidate_forwards_needed": int(need),
-                                  "rollout_steps_per_s": need / dt,
+                                  # effective: the candidate-forwards the reference's loop would run (every candidate stepped
+                                  # action_repeat times) over this time; executed: what the engine actually ran (prefix sharing)
+                                  "effective_rollout_steps_per_s": need / dt, "executed_rollout_steps_per_s": ex / dt,
                                   "best_reward": float(res["best_eval_output"]["reward_seqs"].mean())}), flush=True)
 
 
