@@ -20,14 +20,15 @@ def running_cost(state, action, state_cur, error_func, penalty_func, bbox, group
     bsz, n_look_forward = state.shape[0], state.shape[1]
     state_flat = state.reshape(bsz * n_look_forward, state.shape[2], state.shape[3])
     dev = state.device
-    error = error_func(state_flat).reshape(bsz, n_look_forward).to(torch.float32).contiguous()      # :35-36
-    collision_penalty = penalty_func(state, action, state_cur).to(torch.float32).contiguous()       # :39
+    # (.to(dev): raw pointers go to a HIP kernel below - a callable that returns a CPU tensor must not hand it a host address)
+    error = error_func(state_flat).reshape(bsz, n_look_forward).to(dev, torch.float32).contiguous()      # :35-36
+    collision_penalty = penalty_func(state, action, state_cur).to(dev, torch.float32).contiguous()       # :39
     assert collision_penalty.shape == (bsz, n_look_forward)
     st = state_stats(state_flat)                                                       # :41-44 in one pass: (B*H, 5)
     # :37, :45-53 in ONE launch (csrc/ag_cost.hip: k_reward): error_weight = 2.0 / (error.max() + 1e-6) formed in double
     # precision and rounded to fp32 only when it scales the error, as the reference's Python float does; the box penalty; the
     # two means; the reward.  A sharded batch all-reduces the error maximum first and hands it in.
-    emax = None if group is None else _global_max(error, group).reshape(1).to(torch.float32).contiguous()
+    emax = None if group is None else _global_max(error, group).reshape(1).to(dev, torch.float32).contiguous()
     bb = torch.as_tensor(bbox).to("cpu", torch.float64)
     bbox4 = (C.c_double * 4)(float(bb[0, 0]), float(bb[0, 1]), float(bb[1, 0]), float(bb[1, 1]))
     reward = torch.empty(bsz, device=dev, dtype=torch.float32)

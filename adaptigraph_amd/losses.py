@@ -100,7 +100,7 @@ def cloth_penalty(state_pred, action, state_init, sim_real_ratio=10.0, group=Non
     dev = raw.device
     eng = default_engine(dev)
     # :62-63 in one launch; a sharded batch all-reduces the maximum first and hands it in
-    dmax = None if group is None else _global_max(raw[..., 1], group).reshape(1).to(torch.float32).contiguous()
+    dmax = None if group is None else _global_max(raw[..., 1], group).reshape(1).to(dev, torch.float32).contiguous()
     out = torch.empty(raw.shape[:2], device=dev, dtype=torch.float32)
     eng.check(eng.lib.ag_cost_cloth_combine(eng.ctx, current_stream(dev), ptr(raw), ptr(dmax), raw.shape[0] * raw.shape[1], ptr(out)))
     return out

@@ -437,6 +437,7 @@ def main():
     one_step()
     sync_all()
     share_counts = eng.share_counts()                       # (base edges, slots served by the shared table, slots encoded per candidate)
+    fwd_executed, fwd_needed = eng.rollout_counts()          # candidate-forwards of that call (this rank's shard)
     # ---- secondary figure: the opt-in bf16x3 arithmetic (3-way bf16 split on the bf16 matrix pipe, fp32 accumulate;
     # validated at the same 1e-5 parity bar, tests/test_gpu_more.py).  NOT the headline: `value` is exact fp32.
     dt_b3 = None
@@ -578,6 +579,8 @@ def main():
             # SHA-256 of the gathered per-candidate reward vector of the last timed step (fp32 bytes): sharded == unsharded
             # bit for bit (tests/test_gpu_two_ranks.py compares the 2-rank line with the 1-rank line)
             "reward_sha256": __import__("hashlib").sha256(costs.detach().cpu().numpy().tobytes()).hexdigest(),
+            # HIP multiplexes streams onto this many hardware queues; the engine's four + RCCL's need more than the default 4
+            "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
         }
         if multi is not None:
             line["multi_gpu"] = multi
@@ -588,10 +591,23 @@ def main():
         f_exec = E_enc * FLOP_PER_EDGE + Np * (2 * 135000 + 135900) + 8 * Np * Np
         f_ref = Np * 361800 + N_o * 90900 + E * 500100 + 8 * Np * Np
         t_step = dt / args.steps
-        line["end_to_end"] = {"executed_tflops": f_exec * total_steps / t_step / 1e12,
-                              "frac_of_fp32_mfma_peak": f_exec * total_steps / t_step / 1e12 / PEAK_FP32_MFMA_TFLOPS / world,
+        # FLOPs one timed call EXECUTES (rank 0's shard scaled to the whole batch): f_exec per candidate-forward that ran,
+        # minus the edges of the first forward that the shared table served instead of the relation encoder (share_first:
+        # `slots served` edges were NOT encoded, the base graph's were, once)
+        shard = (hi - lo) / B
+        fwd_exec_all = fwd_executed / shard
+        saved_edges = (share_counts[1] - share_counts[0]) / shard if share_counts[0] else 0.0
+        flop_call = f_exec * fwd_exec_all - saved_edges * FLOP_PER_EDGE
+        line["end_to_end"] = {"executed_tflops": flop_call / t_step / 1e12,
+                              "frac_of_fp32_mfma_peak": flop_call / t_step / 1e12 / PEAK_FP32_MFMA_TFLOPS / world,
                               "effective_reference_formulation_tflops": f_ref * total_steps / t_step / 1e12,
-                              "flop_per_step_executed": f_exec, "flop_per_step_reference_formulation": f_ref}
+                              "flop_per_step_executed": f_exec, "flop_per_step_reference_formulation": f_ref,
+                              "flop_per_call_executed": flop_call,
+                              "candidate_forwards_executed": int(round(fwd_exec_all)), "candidate_forwards_needed": int(round(fwd_needed / shard)),
+                              "edges_not_encoded_thanks_to_the_shared_first_forward": int(round(saved_edges)),
+                              "how": "flop_per_call_executed = flop_per_step_executed x candidate_forwards_executed - "
+                                     "edges_not_encoded x flop_per_edge (ag_ctx_rollout_counts / ag_ctx_share_counts of one call of the "
+                                     "timed shape); executed_tflops = that / ms_per_step"}
         # the first forward of the timed call: edges the relation encoder ran over with / without the shared base table
         line["shared_first_forward"] = {"base_edges_encoded_once": share_counts[0], "slots_served_by_the_shared_table": share_counts[1],
                                         "slots_encoded_per_candidate": share_counts[2],

@@ -1,0 +1,239 @@
+"""Per-stream call slots of a context and the planner's chunk loop on top of them (-m gpu; r05).
+
+The reference's planning loop is 40 independent `Planner.trajectory_optimization` calls on one start state, then `merge_res`
+(src/planning/plan.py:241-247, src/planning/real_world/planner.py:234-277, 311-323).  On the engine a call's workspace, launch
+plans and pinned read-back buffers belong to the slot of the CALLER'S STREAM (include/adaptigraph_amd.h), so calls on different
+streams run side by side; `adaptigraph_amd.Planner` deals the loop's calls to a few streams.  Everything here must be IDENTICAL
+BITS to the one-stream, wait-after-every-call execution - a candidate's rollout does not depend on its batch, stream or
+neighbours."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import _ppm, POS_TOL
+from test_gpu_more import _task, _grid, _rope, _actions, _model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ag():
+    import adaptigraph_amd
+    return adaptigraph_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import adaptigraph_oracle
+    return adaptigraph_oracle
+
+
+LIMITS = dict(action_lower_lim=[-4.5, -2.5, -3.14, 0.0], action_upper_lim=[0.0, 4.5, 3.14, 6.0])
+
+
+def test_calls_on_seven_streams_of_one_context_equal_the_synchronous_results(ag, O, dev):
+    """More caller streams than call slots (4): a stream that finds none free takes over the least recently used one after that
+    slot's last call.  Asynchronous calls of three shapes - small (no sharing), prefix-sharing with the base rollout kept in the
+    context and read by calls on OTHER streams, masked-free host-decoded - round-robin over seven streams, nothing waited for in
+    between: every result equals the synchronous call's."""
+    rng = np.random.default_rng(503)
+    W, m = _model(ag, O, "rope", 503, dev)
+    small, big = _rope(150, rng), _rope(600, rng)
+    t_dev = _task("rope", max_nR=40000, **LIMITS)
+    t_host = _task("rope", max_nR=40000)
+    jobs = []
+    for i in range(21):
+        cloud = big if i % 3 == 1 else small
+        B = 96 if i % 3 == 1 else (40 if i % 3 == 0 else 130)
+        a = torch.from_numpy(_actions(cloud, B, 1, rng.integers(1, 6, (B, 1)), rng, spread=2.5))
+        task = t_host if i % 3 == 2 else t_dev
+        jobs.append((torch.from_numpy(cloud).to(dev), a.to(dev) if task is t_dev else a, _ppm(task, "rope")))
+    want = [ag.dynamics(s, a, m, dev, p)["state_seqs"].clone() for s, a, p in jobs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(7)]
+    flags = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in jobs]
+    got = []
+    for i, (s, a, p) in enumerate(jobs):
+        with torch.cuda.stream(streams[i % 7]):
+            got.append(ag.dynamics(s, a, m, dev, p, _sync=False, _overflow_flag=flags[i])["state_seqs"])
+    torch.cuda.synchronize()
+    for i in range(len(jobs)):
+        assert torch.equal(got[i], want[i]), i
+        assert flags[i].tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("device_plan", [False, True])
+def test_a_steady_state_call_allocates_nothing(ag, O, dev, device_plan):
+    """hipMalloc / hipFree / hipHostMalloc are device-wide synchronisation points.  A call slot creates its buffers, events and
+    streams when it first sees a shape; a repeated call of that shape on that stream makes no allocation and no creation at all
+    (ag_ctx_alloc_counts) - with the contact-free prefix (base rollout kept in the context), without it, on one and on two
+    in-library streams."""
+    rng = np.random.default_rng(509)
+    W, m = _model(ag, O, "rope", 509, dev)
+    eng = m.engine(dev)
+    cloud = _rope(600, rng)
+    task = _task("rope", max_nR=40000, **(LIMITS if device_plan else {}))
+    ppm = _ppm(task, "rope")
+    s0 = torch.from_numpy(cloud).to(dev)
+    B = 128
+    acts = [torch.from_numpy(_actions(cloud, B, 1, rng.integers(1, 6, (B, 1)), rng, spread=2.5)) for _ in range(3)]
+    if device_plan:
+        acts = [a.to(dev) for a in acts]
+    for prefix in (-1, 0):
+        for streams in (0, 2):
+            with eng.options(share_prefix=prefix, streams=streams):
+                outs = []
+                for i in range(3):
+                    if i == 2:
+                        before = eng.alloc_counts()
+                    outs.append(ag.dynamics(s0, acts[i], m, dev, ppm)["state_seqs"])
+                assert eng.alloc_counts() == before, (prefix, streams, eng.alloc_counts() - before)
+                with eng.options(share_prefix=0):
+                    assert torch.equal(outs[2], ag.dynamics(s0, acts[2], m, dev, ppm)["state_seqs"])
+
+
+def _planner(ag, m, ppm, dev, cloud, S, H, task, **extra):
+    from adaptigraph_amd.planner import Planner
+    lo = torch.tensor([cloud[:, 0].min() - 1.5, cloud[:, 2].min() - 1.5, -3.14, 2.0], device=dev)
+    hi = torch.tensor([cloud[:, 0].max() + 1.5, cloud[:, 2].max() + 1.5, 3.14, 6.0], device=dev)
+    target = torch.from_numpy(cloud + np.float32([0.2, 0, 0.1])).to(dev)
+    cfg = {"action_dim": 4, "model_rollout_fn": partial(ag.dynamics, model=m, device=dev, ppm_optimizer=ppm),     # plan.py:190
+           "evaluate_traj_fn": partial(ag.running_cost, error_func=partial(ag.chamfer, y=target[None]),
+                                       penalty_func=partial(ag.rope_penalty, sim_real_ratio=10.0),
+                                       bbox=np.array([[-4.5, 0.0], [-2.5, 4.5]])),
+           "sampling_action_seq_fn": partial(ag.sample_action_seq, action_lower_lim=lo, action_upper_lim=hi, n_sample=S,
+                                             device=dev, noise_level=0.3, push_length=task["push_length"]),
+           "clip_action_seq_fn": partial(ag.clip_actions, action_lower_lim=lo, action_upper_lim=hi),
+           "optimize_action_mppi_fn": partial(ag.optimize_action_mppi, reward_weight=500.0, action_lower_lim=lo,
+                                              action_upper_lim=hi, push_length=task["push_length"]),
+           "n_sample": S, "n_look_ahead": H, "n_update_iter": 1, "reward_weight": 500.0, "action_lower_lim": lo,
+           "action_upper_lim": hi, "planner_type": "MPPI", "device": dev, "verbose": False, "noise_level": 0.3,
+           "rollout_best": True}
+    cfg.update(extra)
+    return Planner(cfg), lo, hi
+
+
+def _loop(planner, s0, act_seq, n_chunk):
+    res_all = []
+    for ci in range(n_chunk):                                           # plan.py:241-247
+        planner.chunk_id = ci
+        res = planner.trajectory_optimization(s0, act_seq)
+        res_all.append({k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in res.items()})
+    return planner.merge_res(res_all), res_all
+
+
+def test_planner_loop_dealt_to_streams_equals_the_strict_loop_bitwise(ag, O, dev):
+    """The drop-in as plan.py drives it: `model_rollout_fn = partial(dynamics, model=..., device=..., ppm_optimizer=...)`, 12 x
+    trajectory_optimization + merge_res.  Default (calls dealt to 4 streams, no waiting, winners' rollouts taken out of their
+    batches) against the strict execution (one stream, every call waits for its flags, winners re-rolled with a batch of one):
+    same winner, same rollout, same reward, same per-chunk results, same generator state - bit for bit; 130 x 601 rows, so the
+    contact-free prefix and the kept base rollout are in play too."""
+    rng = np.random.default_rng(521)
+    task = _task("rope", max_nR=40000, **LIMITS)
+    W, m = _model(ag, O, "rope", 521, dev)
+    cloud = _rope(600, rng)
+    s0 = torch.from_numpy(cloud).to(dev)
+    ppm = _ppm(task, "rope")
+    S, n_chunk, H = 130, 12, 1
+    planner, lo, hi = _planner(ag, m, ppm, dev, cloud, S, H, task)
+    assert planner.pipeline_chunks == 4 and planner.reuse_best_rollout       # the defaults for the engine's own dynamics()
+    torch.manual_seed(3)
+    act_seq = torch.rand((H, 4), device=dev) * (hi - lo) + lo
+    results = {}
+    for label, pipe, reuse in (("default", 4, True), ("strict", 0, False), ("two streams, re-rolled", 2, False), ("one stream, reuse", 0, True)):
+        planner.pipeline_chunks, planner.reuse_best_rollout = pipe, reuse
+        torch.manual_seed(4)
+        merged, per_chunk = _loop(planner, s0, act_seq, n_chunk)
+        torch.cuda.synchronize()
+        results[label] = (merged, per_chunk, torch.cuda.get_rng_state(dev))
+    ref = results["strict"]
+    for label, (merged, per_chunk, gen) in results.items():
+        assert torch.equal(gen, ref[2]), label
+        for k in ("act_seq",):
+            assert torch.equal(merged[k], ref[0][k]), (label, k)
+        assert torch.equal(merged["best_model_output"]["state_seqs"], ref[0]["best_model_output"]["state_seqs"]), label
+        assert torch.equal(merged["best_eval_output"]["reward_seqs"], ref[0]["best_eval_output"]["reward_seqs"]), label
+        for ci in range(n_chunk):
+            assert torch.equal(per_chunk[ci]["act_seq"], ref[1][ci]["act_seq"]), (label, ci)
+            assert torch.equal(per_chunk[ci]["best_model_output"]["state_seqs"], ref[1][ci]["best_model_output"]["state_seqs"]), (label, ci)
+            assert torch.equal(per_chunk[ci]["best_eval_output"]["reward_seqs"], ref[1][ci]["best_eval_output"]["reward_seqs"]), (label, ci)
+    # and the chunked entry (one rollout call for all chunks) gives the same
+    planner.pipeline_chunks, planner.reuse_best_rollout = 4, True
+    torch.manual_seed(4)
+    fused = planner.trajectory_optimization_chunked(s0, act_seq, n_chunk)
+    assert torch.equal(fused["act_seq"], ref[0]["act_seq"])
+    assert torch.equal(fused["best_model_output"]["state_seqs"], ref[0]["best_model_output"]["state_seqs"])
+    # the winner against the oracle
+    want = O.dynamics(W, 3, cloud, ref[0]["act_seq"].cpu().numpy()[None], task)["state_seqs"]
+    assert np.abs(ref[0]["best_model_output"]["state_seqs"].cpu().numpy() - want).max() <= POS_TOL
+
+
+def test_exceeds_max_dims_of_a_dealt_call_surfaces_at_merge_res(ag, O, dev):
+    """pad_torch's Exception("Exceeds max dims") (src/dynamics/utils.py:63-65) is raised inside dynamics() in the reference.  A
+    call that is dealt to a side stream does not wait for its flags: the exception surfaces at a later call or - at the latest -
+    at merge_res, where the reference's loop first reads a result back (planner.py:312-314); with pipeline_chunks 0 it is raised
+    by the call itself.  Afterwards the planner and the context are as good as before."""
+    rng = np.random.default_rng(523)
+    W, m = _model(ag, O, "rope", 523, dev)
+    cloud = _rope(120, rng)
+    s0 = torch.from_numpy(cloud).to(dev)
+    tight = _task("rope", max_nR=300, **LIMITS)                  # the rope's own graph has ~1300 edges
+    planner, lo, hi = _planner(ag, m, _ppm(tight, "rope"), dev, cloud, 16, 1, tight)
+    torch.manual_seed(5)
+    act_seq = torch.rand((1, 4), device=dev) * (hi - lo) + lo
+    with pytest.raises(Exception, match="Exceeds max dims"):
+        _loop(planner, s0, act_seq, 3)
+    assert planner._pending == []
+    planner.pipeline_chunks = 0
+    with pytest.raises(Exception, match="Exceeds max dims"):
+        planner.trajectory_optimization(s0, act_seq)
+    ok = _task("rope", max_nR=40000, **LIMITS)
+    planner2, lo, hi = _planner(ag, m, _ppm(ok, "rope"), dev, cloud, 16, 1, ok)
+    merged, _ = _loop(planner2, s0, act_seq, 3)
+    assert torch.isfinite(merged["best_model_output"]["state_seqs"]).all()
+
+
+def test_census_verdict_is_kept_without_waiting_and_revisited(ag, O, dev):
+    """Automatic prefix sharing takes a census of the first forward.  A batch whose pushes all start on the object declines the
+    sharing; calls of the same shape then skip the blocking census (a census goes out that nobody waits for), and when a later
+    batch of that shape holds enough free candidates the sharing comes back within a few calls.  Results never depend on the
+    verdict: every call equals share_prefix = 0 bit for bit."""
+    rng = np.random.default_rng(541)
+    task = _task("rope", max_nR=40000, **LIMITS)
+    W, m = _model(ag, O, "rope", 541, dev)
+    eng = m.engine(dev)
+    cloud = _rope(600, rng)
+    s0 = torch.from_numpy(cloud).to(dev)
+    ppm = _ppm(task, "rope")
+    B = 128
+    reps = rng.integers(2, 6, (B, 1))
+    on = _actions(cloud, B, 1, reps, rng, spread=0.0)
+    on[:, 0, :2] = cloud[rng.integers(0, 600, B)][:, [0, 2]]             # every push starts on the rope
+    far = _actions(cloud, B, 1, reps, rng, spread=0.0)
+    far[:, 0, 0] += 40.0                                                  # nobody ever touches
+    on_d, far_d = torch.from_numpy(on).to(dev), torch.from_numpy(far).to(dev)
+
+    def run(a):
+        out = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]
+        ex, need = eng.rollout_counts()
+        with eng.options(share_prefix=0):
+            assert torch.equal(out, ag.dynamics(s0, a, m, dev, ppm)["state_seqs"])
+        return ex, need
+
+    for _ in range(3):
+        ex, need = run(on_d)
+        assert ex == need                                                 # declined: everybody is stepped
+    shared = []
+    for _ in range(5):
+        ex, need = run(far_d)
+        torch.cuda.synchronize()
+        shared.append(ex < need)
+    assert shared[-1] and any(shared[:4]), shared                          # the standing verdict was lifted by an unwaited census

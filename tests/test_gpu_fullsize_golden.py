@@ -43,10 +43,14 @@ def O():
 # min_clean = what the runs so far produced (r03 logs gpurun_out/r3a, r3k; unchanged since: the later changes are bit-identical):
 # every cloth candidate clean on both action paths, 3 of 4 rope candidates (candidate 0 parts at forward 10, an attributed
 # tie - the rope's smallest selection margin is 1.9e-8), and 0 only for full_granular, where the REFERENCE itself parts
-# from the oracle at forward 18 at a 1e-7 near-tie and the GPU follows the oracle's side
+# from the oracle at forward 18 at a 1e-7 near-tie and the GPU follows the oracle's side.
+# r05 (gpurun_out/r5d): four more candidates of BASELINE configs[2]'s batch, reference records from make_golden.py --fullsize-r05:
+# the GPU stays within 2.9e-6 of the REFERENCE through all 20 forwards on three of them (85, 255, 128 - on both action paths; the
+# numpy oracle stays with the reference on 128 only) and parts at forward 18 on candidate 170, a near-tie in the reference's own
+# distances (its smallest selection margin there is 1.4e-7): min_clean 1 + 2
 @pytest.mark.parametrize("name,material,min_clean", [("full_cloth_a", "cloth", 2), ("full_cloth_flip", "cloth", 2),
-                                                     ("full_granular", "granular", 0), ("full_granular_b", "granular", 0),
-                                                     ("full_granular_c", "granular", 0), ("full_rope", "rope", 3),
+                                                     ("full_granular", "granular", 0), ("full_granular_b", "granular", 1),
+                                                     ("full_granular_c", "granular", 2), ("full_rope", "rope", 3),
                                                      ("full_masked_cloth", "cloth", 2)])
 def test_rollout_vs_reference_at_full_size(ag, O, dev, name, material, min_clean):
     g = load_golden(name)

@@ -267,6 +267,12 @@ def test_costs_vs_reference_golden(ag, dev):
             r = ag.running_cost(t("state"), t("action"), t("state_cur"), error_func=err, penalty_func=pen, bbox=g["bbox"])
             want = g[f"reward::{err_name}::{kind}"]
             assert np.abs(r["reward_seqs"].cpu().numpy() - want).max() < 5e-5 * max(1.0, np.abs(want).max()), (err_name, kind)
+    # a caller's error / penalty callable may return CPU tensors (the reference's signature allows any callable): the values
+    # are moved to the device before their addresses go to the kernel - same reward, no host pointer in a HIP launch
+    err_cpu = lambda x: ag.chamfer(x, t("target")[None]).cpu()
+    pen_cpu = lambda *a: ag.rope_penalty(*a, sim_real_ratio=10.0).cpu().double()
+    r = ag.running_cost(t("state"), t("action"), t("state_cur"), error_func=err_cpu, penalty_func=pen_cpu, bbox=g["bbox"])
+    assert np.abs(r["reward_seqs"].cpu().numpy() - g["reward::chamfer::rope"]).max() < 5e-5 * max(1.0, np.abs(g["reward::chamfer::rope"]).max())
 
 
 def test_chamfer_full_size_vs_oracle(ag, dev):

@@ -103,6 +103,44 @@ def test_contact_free_prefix_is_bit_identical(ag, O, dev, material, cloud_fn, B,
     assert any(c == 0 for c in contacts), contacts              # the batch does hold candidates that never touch
 
 
+def test_over_bound_repeats_are_treated_alike_with_and_without_prefix_sharing(ag, O, dev):
+    """Device-planned calls take the caller's bound of action_repeat (task_config['action_upper_lim'][3]).  A candidate beyond it -
+    also a garbage length like inf or 1e9, at look-ahead step 0 or later - is stepped at most `bound` times and never captured,
+    the asynchronous shim marks its rows NaN and flags[1] reports it; the launch loop stays bounded.  The same with the contact-free
+    prefix as without it (r04's prefix path copied later steps' repeats unclamped into its launch loop), and every other candidate
+    is untouched by its neighbour's garbage."""
+    rng = np.random.default_rng(467)
+    task = _task("rope", max_nR=40000, **LIMITS)                  # bound 9
+    W, m = _model(ag, O, "rope", 467, dev)
+    cloud = _rope(200, rng)
+    B, H = 200, 2
+    reps = rng.integers(1, 9, (B, H))
+    a_np = _actions(cloud, B, H, reps, rng, spread=2.0)
+    a_np[7, 0, 3] = 12.5                                          # beyond the bound at look-ahead step 0
+    a_np[9, 0, 3] = np.inf                                        # garbage
+    a_np[11, 1, 3] = 1.0e9                                        # beyond the bound at look-ahead step 1
+    bad = [7, 9, 11]
+    good = [b for b in range(B) if b not in bad]
+    s0, a = torch.from_numpy(cloud).to(dev), torch.from_numpy(a_np).to(dev)
+    ppm = _ppm(task, "rope")
+    eng = m.engine(dev)
+    outs = {}
+    for sp in (1, 0):
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        with eng.options(share_prefix=sp, device_decode=1):
+            out = ag.dynamics(s0, a, m, dev, ppm, _sync=False, _overflow_flag=flags)["state_seqs"]
+            torch.cuda.synchronize()
+            enq, bound = eng.launch_counts()
+        assert flags[1].item() > 9 and flags[0].item() == 0
+        assert enq <= bound <= 2 * 9 * 4, (enq, bound)             # no launch loop beyond bound x look-ahead steps x chunks
+        assert torch.isnan(out[bad]).all() and torch.isfinite(out[good]).all()
+        outs[sp] = out
+    assert torch.equal(outs[1][good], outs[0][good])
+    clean = torch.from_numpy(a_np[good]).to(dev)
+    with eng.options(share_prefix=0, device_decode=1):
+        assert torch.equal(ag.dynamics(s0, clean, m, dev, ppm)["state_seqs"], outs[0][good])
+
+
 def test_prefix_sharing_when_every_or_no_candidate_touches(ag, O, dev):
     rng = np.random.default_rng(409)
     task = _task("rope", max_nR=40000)
