@@ -30,7 +30,7 @@ EXPORTS = ["ag_abi_version", "ag_ctx_create", "ag_ctx_destroy", "ag_last_error",
            "ag_cost_chamfer", "ag_cost_state_stats", "ag_cost_penalty", "ag_ctx_set_precision", "ag_build_edges_single",
            "ag_edges_apply_tool_rule", "ag_mppi_sample", "ag_mppi_update", "ag_mppi_clip",
            "ag_ctx_set_option", "ag_ctx_get_option", "ag_ctx_rollout_counts", "ag_rollout_actions", "ag_ctx_share_counts", "ag_ctx_launch_counts", "ag_cost_reward", "ag_cost_cloth_combine",
-           "ag_ctx_alloc_counts"]
+           "ag_ctx_alloc_counts", "ag_rollout_work"]
 
 OPTIONS = ["streams", "chunk", "latency", "ragged", "ell_graph", "self_dedupe", "repeat_sort", "edge_wgs", "edge_block_min",
            "enc_persist", "stagger_us", "device_decode", "zigzag", "share_first", "share_prefix", "stream_min_rows", "pipeline_fork"]
@@ -84,6 +84,7 @@ def load():
     lib.ag_rollout.argtypes = [vp, vp, C.POINTER(AgRolloutParams), vp, vp, vp, vp, vp, vp, vp]  # ..., h_repeat, d_phys_vec, d_state_seqs
     lib.ag_rollout_async.argtypes = [vp, vp, C.POINTER(AgRolloutParams), vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ag_rollout_actions.argtypes = [vp, vp, C.POINTER(AgRolloutParams), vp, vp, f32, vp, i32, vp, vp, vp, vp]
+    lib.ag_rollout_work.argtypes = [vp, vp, C.POINTER(AgRolloutParams), vp, vp, f32, vp, i32, vp, vp]
     lib.ag_cost_chamfer.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.ag_cost_state_stats.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.ag_cost_penalty.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]

@@ -73,6 +73,7 @@ struct CallSlot {
     hipEvent_t ev_census = nullptr; bool census_pending = false;   // a census went out on this slot's stream that nobody waited for
     BaseKey census_key{}; int census_B = 0, census_H = 0, census_R = 0;
     hipEvent_t ev_done = nullptr; bool have_done = false;   // end of the slot's last call
+    float* d_work = nullptr; size_t work_cap = 0;   // ag_rollout_work: scratch for the plan kernel's other outputs
     int* d_words = nullptr;      // 64 ints: [0] overflow word of the synchronous entry points, [8..11] census counters
     unsigned long long* d_share_stats = nullptr;      // shared first forward: [0] slots served by the base table, [1] slots encoded per candidate
     static constexpr int kMaxStreams = 4;
@@ -230,6 +231,7 @@ void slot_destroy(ag_ctx* c, CallSlot& s) {
     if (s.d_share_stats) (void)hipFree(s.d_share_stats);
     if (s.d_repeat) (void)hipFree(s.d_repeat);
     if (s.d_plan) (void)hipFree(s.d_plan);
+    if (s.d_work) (void)hipFree(s.d_work);
     if (s.slab.base) (void)hipFree(s.slab.base);
     s = CallSlot();
 }
@@ -932,6 +934,7 @@ struct ActionSrc {
     const float* d_eef_xz = nullptr; const float* d_eef_delta = nullptr; const int32_t* h_repeat = nullptr;   // host plan
     const float* d_action = nullptr; float push_length = 0.f; const float* h_tool_off = nullptr; int max_repeat = 0;
     float* d_action_seqs = nullptr;                                                                            // device plan
+    int32_t* h_work = nullptr;    // ag_rollout_work: plan only - forwards each candidate would be stepped, to the host; nothing is rolled out
 };
 
 int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0, const uint8_t* d_obj_mask,
@@ -940,7 +943,8 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     const float* d_eef_xz = src.d_eef_xz; const float* d_eef_delta = src.d_eef_delta; const int32_t* h_repeat = src.h_repeat;
     if (!c) return AG_ERR_INVALID;
     if (!c->have_w) return fail(c, AG_ERR_NO_WEIGHTS, "ag_rollout before ag_ctx_load_weights");
-    if (!p || !d_state0 || !d_state_seqs || !d_overflow_flag || (!dev_plan && (!d_eef_xz || !d_eef_delta || !h_repeat)) ||
+    const bool work_only = src.h_work != nullptr;
+    if (!p || !d_state0 || (!d_state_seqs && !work_only) || !d_overflow_flag || (!dev_plan && (!d_eef_xz || !d_eef_delta || !h_repeat)) ||
         (dev_plan && (!src.d_action_seqs || (p->M > 1 && !src.h_tool_off))))
         return fail(c, AG_ERR_INVALID, "ag_rollout: null pointer");
     if (dev_plan && (src.max_repeat < 0 || src.max_repeat > 1024 || p->M > 8))
@@ -972,7 +976,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     CallSlot& sl = *slp;
     c->last_slot = (int)(slp - c->slots);
     c->d_share_nns = nullptr;                                // pointed into a workspace of an earlier call
-    HIPCHK(c, hipMemsetAsync(d_state_seqs, 0, (size_t)p->B * p->H * p->N_o * 3 * 4, st));   // forward_dynamics.py:32
+    if (d_state_seqs) HIPCHK(c, hipMemsetAsync(d_state_seqs, 0, (size_t)p->B * p->H * p->N_o * 3 * 4, st));   // forward_dynamics.py:32
 
     const int k = std::min(N, p->topk);
     const long bound = (long)N * (k + p->M);                 // in-degree <= topk + M (radius-AND-top-k, then tool rule)
@@ -1012,6 +1016,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         Bc = (p->B + n_chunks - 1) / n_chunks;
     }
     if (p->B <= 1) ns = 1;
+    if (work_only) { ns = 1; Bc = 1; }                       // plan only: the one workspace a base rollout needs
     const int slices = pick_slices(c, Bc, N);
     const int ell = edge_ell_stride(N, p->topk);
     const int Ba = Bc + (ragged ? 1 : 0);                    // candidate slots per workspace
@@ -1069,6 +1074,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     // (with the prefix sharing only the candidates that touch at once start from the start state: EdgeArgs::share_start)
     bool share = c->opt.share_first != 0 && p->y_mode == 0 && !d_obj_mask && ell_full && p->topk < p->N_o && k <= 255;
     if (c->opt.share_first < 0 && p->B < 8) share = false;   // a handful of candidates: the base build costs more than it saves
+    if (work_only) share = false;
     {   // launches small enough for the latency-mode propagate chains (ag_lat.hip) keep their own C rows
         GraphBufs gt{};
         gt.B = std::min(Bc, p->B); gt.N = N; gt.n_his = n_his; gt.wb3 = c->precision == 1 ? c->d_wb3 : nullptr;
@@ -1091,6 +1097,8 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         b_eef = sl.slab.take<float>((size_t)5 * p->M);       // parked tool: xz (M,2), delta (M,3)
         b_zero = sl.slab.take<int>(1);
         if (sl.slab.used > sl.slab.cap) return fail(c, AG_ERR_INVALID, "internal: workspace carve overflow");
+    }
+    if (prefix || work_only) {
         if (sl.rep_pin_cap < 2 * nrep + 8) {                 // pinned read-back of the contact plan: [forwards left | repeat | flag, census x4]
             if (sl.h_rep_pin) HIPCHK(c, pin_free(c, sl.h_rep_pin));
             sl.h_rep_pin = nullptr; sl.rep_pin_cap = 0;
@@ -1235,7 +1243,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             if (h_cnt[3] == 0 && c->base_cache_R >= R_base) { base_cached = true; plan_done = true; }   // a kept base rollout is free: share
             else {
                 // another start state (or a longer push than the kept rollout covers): what the plan above wrote is void
-                HIPCHK(c, hipMemsetAsync(d_state_seqs, 0, (size_t)p->B * p->H * p->N_o * 3 * 4, st));
+                if (d_state_seqs) HIPCHK(c, hipMemsetAsync(d_state_seqs, 0, (size_t)p->B * p->H * p->N_o * 3 * 4, st));
                 if (h_cnt[1] - h_cnt[0] < std::max(64, 8 * R_base)) prefix = false;
             }
         } else if (declined) {
@@ -1396,9 +1404,28 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             c->d_plan_sums = nullptr;
         }
         c->fwd_executed = base_cached ? 0 : R_base;          // the base rollout's forwards (none when an earlier call's is re-used)
-        rc = host_plan(sl.h_rep_pin);                         // launch order and sizes from the forwards that are LEFT
-        if (rc) return rc;
+        if (!work_only) {
+            rc = host_plan(sl.h_rep_pin);                     // launch order and sizes from the forwards that are LEFT
+            if (rc) return rc;
+        }
         d_start = b_start; d_base_states = b_states; d_base_y = b_y;
+    }
+    if (work_only) {
+        // forwards candidate b would be stepped by the call this one stands for: what is left of look-ahead step 0 after its first
+        // contact (prefix sharing in play) or all of it, plus the later steps' repeats, each at most the caller's bound
+        if (!prefix) {
+            HIPCHK(c, hipMemcpyAsync(sl.h_rep_pin, pl_repeat, nrep * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipEventRecord(sl.ev_plan, st));
+            HIPCHK(c, hipEventSynchronize(sl.ev_plan));
+        }
+        for (int b = 0; b < p->B; ++b) {
+            long w = 0;
+            for (int li = 0; li < p->H; ++li) w += std::min(std::max(0, sl.h_rep_pin[(size_t)b * p->H + li]), R);
+            src.h_work[b] = (int32_t)w;
+        }
+        c->d_plan_sums = nullptr;
+        slot_release(&sl, st, capturing);
+        return AG_OK;
     }
     hipStream_t streams[ag_ctx::kMaxStreams] = {st, st, st, st};
     if (ns > 1) {
@@ -1554,6 +1581,30 @@ int ag_rollout_actions(ag_ctx* c, void* stream, const ag_rollout_params* p, cons
     src.d_action = d_action; src.push_length = push_length; src.h_tool_off = h_tool_offsets; src.max_repeat = max_repeat;
     src.d_action_seqs = d_action_seqs;
     return rollout_impl(c, stream, p, d_state0, nullptr, src, d_phys_vec, d_state_seqs, d_flags);
+}
+
+int ag_rollout_work(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0, const float* d_action,
+                    float push_length, const float* h_tool_offsets, int32_t max_repeat, const float* d_phys_vec, int32_t* h_work) {
+    if (!c) return AG_ERR_INVALID;
+    if (!d_action || !h_work) return fail(c, AG_ERR_INVALID, "ag_rollout_work: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(c, hipSetDevice(c->device));
+    CallSlot* sl = nullptr;
+    int rc = slot_acquire(c, st, false, &sl);
+    if (rc) return rc;
+    const size_t nrep = (size_t)p->B * p->H;
+    // scratch for what the plan kernel writes besides the plan: decoded actions (B,H,4) and the two flag words
+    if (sl->work_cap < nrep * 4 + 64) {
+        if (sl->d_work) HIPCHK(c, dev_free(c, sl->d_work));
+        sl->d_work = nullptr; sl->work_cap = 0;
+        HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&sl->d_work), (nrep * 4 + 64) * 4 * 2));
+        sl->work_cap = (nrep * 4 + 64) * 2;
+    }
+    HIPCHK(c, hipMemsetAsync(sl->d_work, 0, 64 * 4, st));
+    ActionSrc src;
+    src.d_action = d_action; src.push_length = push_length; src.h_tool_off = h_tool_offsets; src.max_repeat = max_repeat;
+    src.d_action_seqs = sl->d_work + 64; src.h_work = h_work;
+    return rollout_impl(c, stream, p, d_state0, nullptr, src, d_phys_vec, nullptr, reinterpret_cast<int32_t*>(sl->d_work));
 }
 
 int ag_rollout(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0, const uint8_t* d_obj_mask,

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(CT) void k_contact_plan(ContactPlan p) {
         p.rep_eff[(long)b * p.H] = d ? rep - d + 1 : 0;
         p.start[b] = d ? d - 1 : 0;
     }
-    if (!d && rep >= 1) {                                    // never touched: the capture of forward `rep` is the base state S_rep
+    if (!d && rep >= 1 && p.state_seqs) {                    // never touched: the capture of forward `rep` is the base state S_rep
         const float* S = p.base_states + (long)rep * p.N_o * 3;
         float* out = p.state_seqs + (long)b * p.H * p.N_o * 3;
         for (int k = tid; k < p.N_o * 3; k += CT) out[k] = S[k];

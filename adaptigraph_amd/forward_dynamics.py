@@ -152,6 +152,42 @@ def _run_device_actions(model, eng, dev, task, ppm_optimizer, physics_param, act
 
 
 @torch.no_grad()
+def rollout_work(state, action, model, device, ppm_optimizer, physics_param=None):
+    """Model forwards each candidate of `dynamics(state, action, ...)` would be stepped on this engine, WITHOUT rolling anything
+    out: (B,) int64 numpy.  With the contact-free prefix in play a candidate counts only the forwards from its first contact on
+    (0 if it never touches); otherwise its action_repeat summed over the look-ahead steps.  For cutting work-balanced shards of a
+    candidate batch across GPUs (sharding.sharded_candidate_rewards(work_fn=...)): every rank calls it on the FULL batch and gets
+    the same numbers - no exchange.  The tool-free base rollout it computes stays in the context for the dynamics() call that
+    follows.  Needs GPU-resident (or movable) actions and a task config that bounds the push length; else returns the repeats."""
+    import numpy as np
+    task = ppm_optimizer.task_config
+    dev = _require_gpu(device)
+    B, H = action.shape[0], action.shape[1]
+    bound = _repeat_bound(task)
+    eng = model.engine(dev) if isinstance(model, DynamicsPredictor) else None
+    if eng is None or bound is None or not (0 <= bound <= 1024) or ppm_optimizer.eef_num > 8 or eng.get_option("device_decode") == 0:
+        _, repeat = decode_action(action.detach().to("cpu", torch.float32), push_length=task["push_length"])
+        return repeat.clamp(min=0).sum(1).to(torch.int64).numpy()
+    assert int(task["n_his"]) == model.n_his
+    state0 = state.detach().to(dev, torch.float32).contiguous()
+    N_o, M = state0.shape[0], ppm_optimizer.eef_num
+    pts = task["pusher_points"]
+    if len(pts) != M or M not in (1, 5):
+        raise NotImplementedError("pusher not implemented")
+    grip = bool(task["gripper_enable"])
+    phys_val, phys_vec = _physics(ppm_optimizer, physics_param, N_o, dev)
+    p = _lib.AgRolloutParams(B, H, N_o, M, int(task["topk"]), int(bool(task["connect_tools_all"])), int(task["max_nR"]), 0,
+                             float(ppm_optimizer.adj_thresh), float(0.01 * task["sim_real_ratio"]) if grip else 0.0,
+                             int(grip), phys_val)
+    offs = (C.c_float * 8)(*([0.0] + [float(pts[k][1]) * task["sim_real_ratio"] for k in range(1, M)] + [0.0] * (8 - M)))
+    act = action.detach().to(dev, torch.float32).contiguous()
+    work = np.zeros(B, np.int32)
+    eng.check(eng.lib.ag_rollout_work(eng.ctx, current_stream(dev), C.byref(p), ptr(state0), ptr(act), float(task["push_length"]),
+                                      offs, int(bound), ptr(phys_vec), work.ctypes.data_as(C.c_void_p)))
+    return work.astype(np.int64)
+
+
+@torch.no_grad()
 def dynamics(state, action, model, device, ppm_optimizer, physics_param=None, _sync=True, _overflow_flag=None):
     """state (N_o,3), action (B,H,4) -> {'state_seqs': (B,H,N_o,3), 'action_seqs': (B,H,4)}"""
     task = ppm_optimizer.task_config

@@ -87,18 +87,40 @@ def sharded_rollout_costs(rollout_fn, cost_fn, actions: torch.Tensor, group=None
     return all_gather_costs(local, actions.shape[0], group, bounds=bounds)
 
 
-def sharded_candidate_rewards(actions: torch.Tensor, rollout_fn, reward_fn, group=None) -> torch.Tensor:
+# what a candidate costs beside its model forwards (plan kernels, slot init / the copy of a base state), in forwards: keeps a
+# shard of candidates that are never stepped from growing without bound
+WORK_FLOOR = 0.25
+
+
+def work_balanced_bounds(work, world: int):
+    """[(lo, hi)] per rank: contiguous shards of the candidate batch cut by WORK (model forwards per candidate, e.g.
+    forward_dynamics.rollout_work) instead of by count.  With the contact-free prefix a candidate's work is 0 .. action_repeat
+    forwards depending on its first contact (the shipped rope sampler: 79 % of the pushes never touch), so count-balanced shards
+    can differ several-fold in work.  Every rank computes the same cuts from the same numbers."""
+    import numpy as np
+    w = np.asarray(work, dtype=np.float64) + WORK_FLOOR
+    return [shard_bounds_weighted(w, world, r) for r in range(world)]
+
+
+def sharded_candidate_rewards(actions: torch.Tensor, rollout_fn, reward_fn, group=None, work_fn=None) -> torch.Tensor:
     """One MPC evaluation of a candidate batch sharded over the ranks of `group` - the step bench.py times.
 
     actions (B, H, 4): the FULL batch, identical on every rank (same seed).  rollout_fn(actions_local) -> state_seqs of
     the local shard; reward_fn(state_seqs, actions_local) -> (b,) rewards (any batch-global quantity inside it - the
     error maximum of running_cost, the cloth penalty's distance maximum - must be all-reduced by the callee, cf.
     losses._global_max).  Returns the (B,) reward vector of the whole batch on every rank: contiguous shards, one
-    all-gather of B/G floats per rank, nothing else crosses ranks."""
+    all-gather of B/G floats per rank, nothing else crosses ranks.
+    work_fn(actions) -> (B,) work per candidate, identical on every rank (forward_dynamics.rollout_work bound to the model):
+    shards are then cut by work (work_balanced_bounds) instead of by count; None / one rank: count-balanced."""
     distributed = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
-    lo, hi = shard_bounds(actions.shape[0], world, rank)
+    bounds = None
+    if work_fn is not None and world > 1:
+        bounds = work_balanced_bounds(work_fn(actions), world)
+        lo, hi = bounds[rank]
+    else:
+        lo, hi = shard_bounds(actions.shape[0], world, rank)
     local = actions[lo:hi]
     rewards = reward_fn(rollout_fn(local), local)
-    return all_gather_costs(rewards.contiguous(), actions.shape[0], group)
+    return all_gather_costs(rewards.contiguous(), actions.shape[0], group, bounds=bounds)

@@ -29,6 +29,7 @@
  *   - WHICH ENTRY POINTS BLOCK THE HOST, and when (everything else only enqueues):
  *       ag_ctx_load_weights, ag_ctx_set_precision     always (host repack + copies)
  *       ag_forward, ag_rollout                        once, at the end: they return the overflow verdict (AG_ERR_MAX_NR)
+ *       ag_rollout_work                               for its plan (and a base rollout, if none is kept): it returns host numbers
  *       ag_ctx_rollout_counts (after a device-planned call without prefix sharing), ag_ctx_share_counts   wait for the device
  *       ag_rollout_async, ag_rollout_actions          only when the contact-free prefix is in play (option "share_prefix";
  *           y_mode 0, by default batches of >= 64 candidates and >= 32768 rows), and then for SMALL plan kernels at the start
@@ -298,6 +299,17 @@ int ag_rollout_async(ag_ctx* ctx, void* stream, const ag_rollout_params* p, cons
 int ag_rollout_actions(ag_ctx* ctx, void* stream, const ag_rollout_params* p, const float* d_state0, const float* d_action,
                        float push_length, const float* h_tool_offsets, int32_t max_repeat, const float* d_phys_vec,
                        float* d_state_seqs, float* d_action_seqs, int32_t* d_flags);
+
+/* The work an ag_rollout_actions call on (d_state0, d_action) would do, per candidate, WITHOUT rolling anything out:
+ * h_work[b] (HOST, (B,) int32) = model forwards candidate b would be stepped = sum over look-ahead steps of min(action_repeat,
+ * max_repeat), where look-ahead step 0 counts only the forwards from the candidate's first contact on when the contact-free
+ * prefix applies to the batch (option "share_prefix": a candidate that never touches counts 0).  Runs the plan kernels and, if
+ * none is kept for this start state, the tool-free base rollout - which then stays in the ctx for the rollout call that follows.
+ * For cutting WORK-balanced shards of a candidate batch across GPUs (adaptigraph_amd/sharding.py): every rank calls
+ * it on the full batch and gets the same numbers, no exchange.  The reference has no counterpart (one device, plan.py:87).
+ * Arguments as ag_rollout_actions.  Synchronous (waits for the plan). */
+int ag_rollout_work(ag_ctx* ctx, void* stream, const ag_rollout_params* p, const float* d_state0, const float* d_action,
+                    float push_length, const float* h_tool_offsets, int32_t max_repeat, const float* d_phys_vec, int32_t* h_work);
 
 /* ---- Per-candidate cost functions: SURVEY §8(f) rank 1 (reference src/planning/losses.py, src/planning/plan.py:27-59) ---- */
 

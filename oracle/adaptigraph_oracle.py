@@ -449,6 +449,53 @@ def dynamics_masked(W, pstep, state_init, state_mask, action, task, physics_para
     return {"state_seqs": out, "action_seqs": dec}
 
 
+def rollout_work(W, pstep, state, action, task, physics_param=0.5):
+    """Model forwards per candidate that remain once the forwards BEFORE its first tool contact are taken from one tool-free
+    base rollout (the engine's contact-free prefix; checker for adaptigraph_amd.rollout_work / csrc/ag_graph.hip: k_contact_plan).
+    Property of the reference it rests on: a tool takes part in an edge only if some object particle lies inside its radius -
+    the radius test of graph.py:251-267 comes before top-k, and connect_tools_all's tool -> object edges are all-or-nothing on
+    such a pair (:276-286) - so until then the object particles evolve as without a tool (forward_dynamics.py:156-176).
+    -> (work (B,) int64, first (B,) int64): work = repeat - first + 1 for look-ahead step 0 (0 when it never touches) + the
+    repeats of the later steps; first = 1-based forward of the first contact at look-ahead step 0, 0 = never."""
+    state = np.asarray(state, F32)
+    action = np.asarray(action, F32)
+    B, H, _ = action.shape
+    N_o = state.shape[0]
+    dec, rep = decode_action(action, task["push_length"])
+    xz, delta = tool_keypoints(dec, action[..., 2], task)
+    M = xz.shape[2]
+    R = int(max(0, rep[:, 0].max()))
+    tr = []
+    far = np.full((M, 2), 1.0e6, F32)                                       # a tool out of every particle's reach that stays there
+    if R > 0:
+        _rollout_candidate(W, pstep, state, np.ones(N_o, bool), far, np.zeros((M, 3), F32), R, task, "min",
+                           np.asarray(physics_param, F32), 1 << 30, tr)
+    S = [state] + [t["pred_pos"] for t in tr]                                # S_0 .. S_R
+    grip = F32(0.01 * task["sim_real_ratio"]) if task["gripper_enable"] else None
+    base_y = [F32(s[:, 1].min()) if grip is None else F32(F32(s[:, 1].min()) + grip) for s in S]    # forward_dynamics.py:40,163,167
+    thr2 = F32(task["adj_thresh"]) * F32(task["adj_thresh"])                # graph.py:248-250
+    work = np.zeros(B, np.int64)
+    first = np.zeros(B, np.int64)
+    for b in range(B):
+        r0 = int(max(0, rep[b, 0]))
+        tx, tz = xz[b, 0, :, 0].copy(), xz[b, 0, :, 1].copy()
+        d = 0
+        for ai in range(1, r0 + 1):                                         # graph of forward ai: objects S_(ai-1), tool after ai-1 advances
+            P = S[ai - 1]
+            for m in range(M):
+                dx, dy, dz = P[:, 0] - tx[m], P[:, 1] - base_y[ai - 1], P[:, 2] - tz[m]
+                dis = (dx * dx + dy * dy) + dz * dz                          # graph.py:251-252 (fp32, this order)
+                if ((dis - thr2) < 0).any():                                # :267
+                    d = ai
+                    break
+            if d:
+                break
+            tx, tz = (tx + delta[b, 0, :, 0]).astype(F32), (tz + delta[b, 0, :, 2]).astype(F32)   # forward_dynamics.py:164
+        first[b] = d
+        work[b] = (r0 - d + 1 if d else 0) + int(np.maximum(rep[b, 1:], 0).sum())
+    return work, first
+
+
 # --------------------------------------------------------------------------- helpers shared by tests / bench
 def weights_from_npz(npz):
     return {k[3:]: np.asarray(npz[k], F32) for k in npz.files if k.startswith("w::")}

@@ -237,3 +237,34 @@ def test_census_verdict_is_kept_without_waiting_and_revisited(ag, O, dev):
         torch.cuda.synchronize()
         shared.append(ex < need)
     assert shared[-1] and any(shared[:4]), shared                          # the standing verdict was lifted by an unwaited census
+
+
+def test_rollout_work_is_what_the_rollout_then_executes(ag, O, dev):
+    """adaptigraph_amd.rollout_work (ag_rollout_work): forwards per candidate WITHOUT rolling anything out - with the contact-free
+    prefix in play only those from a candidate's first contact on.  Exactly what the dynamics() call that follows executes
+    (ag_ctx_rollout_counts; the base rollout it computed is kept and re-used), equal to the oracle's restatement of the contact
+    plan, and the plain repeat sums when the sharing is off or the batch too small for it."""
+    rng = np.random.default_rng(547)
+    task = _task("rope", max_nR=40000, **LIMITS)
+    W, m = _model(ag, O, "rope", 547, dev)
+    eng = m.engine(dev)
+    cloud = _rope(600, rng)
+    s0 = torch.from_numpy(cloud).to(dev)
+    ppm = _ppm(task, "rope")
+    B, H = 160, 2
+    reps = rng.integers(1, 6, (B, H))
+    a_np = _actions(cloud, B, H, reps, rng, spread=2.5)
+    a = torch.from_numpy(a_np).to(dev)
+    work = ag.rollout_work(s0, a, m, dev, ppm)
+    assert work.shape == (B,) and work.dtype == np.int64
+    out = ag.dynamics(s0, a, m, dev, ppm)["state_seqs"]
+    ex, need = eng.rollout_counts()
+    assert need == int(reps.sum()) and ex == int(work.sum()) < need, (ex, int(work.sum()), need)     # base rollout kept: not re-run
+    with eng.options(share_prefix=0):
+        assert torch.equal(out, ag.dynamics(s0, a, m, dev, ppm)["state_seqs"])
+        assert np.array_equal(ag.rollout_work(s0, a, m, dev, ppm), reps.sum(1))
+    want, first = O.rollout_work(W, 3, cloud, a_np, task)
+    assert (work != want).sum() <= 1, np.nonzero(work != want)            # (device cos/sin in the decode: a contact at the radius may move)
+    assert (first == 0).any() and (first > 1).any()
+    small = ag.rollout_work(s0, a[:32], m, dev, ppm)                      # below the automatic threshold (64 candidates): no sharing
+    assert np.array_equal(small, reps[:32].sum(1))

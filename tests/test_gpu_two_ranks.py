@@ -83,3 +83,32 @@ def test_two_ranks_on_one_gpu_equal_one_rank_bitwise():
     assert l2["value"] > 0 and l2["scaling"] == "strong"
     mg = l2["multi_gpu"]                                                 # per-rank times and the exchange's latency, for a real SCALE run
     assert mg["candidates_per_rank"] == [32, 32] and len(mg["per_rank_ms_per_step"]) == 2 and mg["exchange_us_per_step"] > 0
+
+
+def test_work_balanced_shards_of_the_planner_workload_on_two_ranks():
+    """The shipped planner's pushes (uniform over the action box: most never reach the rope) sharded over two ranks by WORK -
+    forwards left per candidate from adaptigraph_amd.rollout_work, identical on every rank, no exchange - on the one GPU of the
+    box (gloo): the gathered reward vector equals the count-balanced one's and the one-rank evaluation's bit for bit, the two
+    shards hold different numbers of candidates and about the same work."""
+    env = dict(_clean_env(), AG_SHARD_CANDIDATES="3000")
+    tool = os.path.join(ROOT, "tools", "two_rank_planner_shards.py")
+    one = subprocess.run([sys.executable, tool], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), tool],
+                         env=dict(env, AG_BENCH_SHARE_GPU="1"), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l1["world"] == 1 and l2["world"] == 2
+    assert l2["reward_sha256_work_balanced"] == l2["reward_sha256_count_balanced"] == l1["reward_sha256_work_balanced"]
+    assert 0.5 < l2["never_touch_fraction"] < 0.95
+    wb, cb = l2["work_balanced"], l2["count_balanced"]
+    f = wb["forwards_per_rank"]
+    assert abs(f[0] - f[1]) <= 0.1 * max(f) + 16, f                       # cut by work: within 10 % (+ one candidate's repeats)
+    n = [r["n"] for r in wb["per_rank"]]
+    assert sum(n) == 3000 and n == [b - a for a, b in wb["bounds"]]
+    # what each rank executed = its candidates' forwards left (+ nothing for the kept base rollout on the second pass)
+    assert [r["executed"] for r in wb["per_rank"]] == f, (wb["per_rank"], f)
+    print(f"2 ranks, {l2['never_touch_fraction']:.0%} never touch: work-balanced forwards {f} (candidates {n}), count-balanced "
+          f"{cb['forwards_per_rank']}")

@@ -164,3 +164,125 @@ def test_two_rank_gloo_mpc_step_matches_unsharded():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert [r[:2] for r in res] == [(0, True), (1, True)] and res[0][2] == res[1][2]
+
+
+# ------------------------------------------------------------------------------------- work-balanced shards (r05)
+# With the contact-free prefix a candidate's work on the engine is 0 .. action_repeat forwards, depending on when its tool first
+# touches the object.  Shards cut by candidate COUNT can then differ several-fold in work; sharding.work_balanced_bounds cuts them
+# by forwards left (adaptigraph_amd.rollout_work on the GPU; here the oracle's restatement of it).  The reference has no multi-GPU
+# code (plan.py:87: one device); its sampler is what makes the imbalance (plan_utils.py:48-50: uniform over the action box).
+def _rope_case(n, rng):
+    t = np.linspace(0, 1, n)
+    p = np.stack([-3.5 + 2.5 * t, 0 * t, 1.0 + 0.5 * np.sin(6 * t)], 1)
+    cloud = (p + rng.normal(0, 0.01, p.shape)).astype(np.float32)
+    task = dict(adj_thresh=0.5, topk=10, connect_tools_all=False, sim_real_ratio=10, push_length=0.1, gripper_enable=False,
+                max_n=1, max_nR=8000, n_his=4, eef_num=1, material="rope", pusher_points=[[0.0, 0.0, 0.12]])
+    return cloud, task
+
+
+def _shipped_rope_samples(B, rng):
+    lo, hi = np.float32([-4.5, -2.5, -3.14, 5.0]), np.float32([0.0, 4.5, 3.14, 15.0])     # planning/rope.yaml:28-29
+    return (rng.random((B, 1, 4), dtype=np.float32) * (hi - lo) + lo).astype(np.float32)     # plan_utils.py:48-50
+
+
+def test_oracle_rollout_work_agrees_with_the_oracles_own_edge_lists():
+    from oracle import adaptigraph_oracle as O
+    rng = np.random.default_rng(11)
+    W = O.random_weights(11)
+    cloud, task = _rope_case(60, rng)
+    a = _shipped_rope_samples(40, rng)
+    a[:, 0, 3] = rng.integers(3, 8, 40) + 0.5
+    a[:8, 0, 0] = cloud[30, 0] + rng.uniform(-0.9, 0.9, 8)                  # some start near the rope: contact after a few forwards
+    a[:8, 0, 1] = cloud[30, 2] + rng.uniform(-0.9, 0.9, 8)
+    work, first = O.rollout_work(W, 3, cloud, a, task)
+    tr = []
+    O.dynamics(W, 3, cloud, a, task, trace=tr)
+    N_o = cloud.shape[0]
+    for b in range(40):
+        hit = next((f + 1 for f, rec in enumerate(tr[b]) if ((rec["recv"] >= N_o) | (rec["send"] >= N_o)).any()), 0)
+        assert first[b] == hit, (b, first[b], hit)
+        rep = int(a[b, 0, 3])
+        assert work[b] == (rep - hit + 1 if hit else 0)
+    assert (first == 0).any() and (first > 1).any() and (first == 1).any(), first
+
+
+def test_work_balanced_shards_on_the_shipped_rope_sampler():
+    """2000 pushes drawn as the reference's planner draws them over the rope task's action box, rope of 200 particles: most
+    never touch.  Work-balanced shards stay within 10 % of each other in work; count-balanced ones do not."""
+    from oracle import adaptigraph_oracle as O
+    from adaptigraph_amd.sharding import work_balanced_bounds, WORK_FLOOR
+    rng = np.random.default_rng(12)
+    W = O.random_weights(12)
+    cloud, task = _rope_case(200, rng)
+    a = _shipped_rope_samples(2000, rng)
+    work, first = O.rollout_work(W, 3, cloud, a, task)
+    free = float((first == 0).mean())
+    assert 0.6 < free < 0.95, free                                           # (DESIGN section 3.0: 79 % on the bench planner's cloud)
+    cost = work + WORK_FLOOR
+    for world in (2, 4, 8):
+        bounds = work_balanced_bounds(work, world)
+        assert bounds[0][0] == 0 and bounds[-1][1] == 2000 and all(x[1] == y[0] for x, y in zip(bounds, bounds[1:]))
+        loads = np.array([cost[lo:hi].sum() for lo, hi in bounds])
+        even = np.array([cost[lo:hi].sum() for lo, hi in (shard_bounds(2000, world, r) for r in range(world))])
+        print(f"world {world}: work-balanced max/mean {loads.max() / loads.mean():.3f}, count-balanced {even.max() / even.mean():.3f}, "
+              f"{free:.0%} of the pushes never touch")
+        assert loads.max() / loads.mean() <= 1.10 and loads.min() / loads.mean() >= 0.90, (world, loads)
+    assert even.max() / even.mean() > 1.10                                   # (at 8 ranks the count-balanced split is visibly worse)
+
+
+def _work_worker(rank, world, port, B, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import adaptigraph_oracle as O
+    from oracle import costs_oracle as Cc
+    from adaptigraph_amd.sharding import sharded_candidate_rewards, work_balanced_bounds
+    from adaptigraph_amd.losses import _global_max
+    rng = np.random.default_rng(13)                       # every rank builds the same inputs
+    W = O.random_weights(13)
+    cloud, task = _rope_case(48, rng)
+    target = (cloud + np.float32([0.3, 0, 0.2])).astype(np.float32)
+    acts = _shipped_rope_samples(B, rng)
+    acts[:, 0, 3] = rng.integers(2, 5, B) + 0.5
+    acts[: B // 4, 0, 0] = cloud[24, 0] + rng.uniform(-0.6, 0.6, B // 4)   # a heavy head: the first quarter touches
+    acts[: B // 4, 0, 1] = cloud[24, 2] + rng.uniform(-0.6, 0.6, B // 4)
+    actions = torch.from_numpy(acts)
+    calls = []
+
+    def rollout(a):                                       # the oracle stands in for the engine (stepping every forward: same values)
+        calls.append(int(a.shape[0]))
+        return torch.from_numpy(O.dynamics(W, 3, cloud, a.numpy(), task)["state_seqs"])
+
+    def work_fn(a):
+        return O.rollout_work(W, 3, cloud, a.numpy(), task)[0]
+
+    def make_reward(group):
+        def reward(seq, a):
+            s = seq.numpy()
+            b, H = s.shape[:2]
+            err = torch.from_numpy(Cc.chamfer(s.reshape(b * H, -1, 3), target[None]).reshape(b, H).astype(np.float32))
+            w = (2.0 / (_global_max(err, group).to(torch.float64) + 1e-6)).to(torch.float32)          # plan.py:37
+            return -w * err[:, -1]
+        return reward
+
+    full = sharded_candidate_rewards(actions, rollout, make_reward(True), work_fn=work_fn)
+    want = make_reward(None)(rollout(actions), actions)
+    bounds = work_balanced_bounds(work_fn(actions), world)
+    ok = torch.equal(full, want) and calls[0] == bounds[rank][1] - bounds[rank][0]
+    uneven = len({hi - lo for lo, hi in bounds}) > 1       # really cut by work: the shards hold different numbers of candidates
+    q.put((rank, bool(ok), bool(uneven)))
+    dist.destroy_process_group()
+
+
+def test_gloo_work_balanced_rewards_match_unsharded():
+    ctx = mp.get_context("spawn")
+    for world in (2, 4):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_work_worker, args=(r, world, port, 24, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=300) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert res == [(r, True, True) for r in range(world)], res
