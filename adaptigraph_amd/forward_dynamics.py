@@ -220,9 +220,14 @@ def dynamics(state, action, model, device, ppm_optimizer, physics_param=None, _s
 
 
 @torch.no_grad()
-def dynamics_masked(state_init, state_mask, action, model, device, ppm_optimizer, physics_param=None):
+def dynamics_masked(state_init, state_mask, action, model, device, ppm_optimizer, physics_param=None, _sync=True,
+                    _overflow_flag=None):
     """state_init (B,max_nobj,3), state_mask (B,max_nobj) bool, action (B,4)
-    -> {'state_seqs': (B,max_nobj,3), 'action_seqs': (B,4)}"""
+    -> {'state_seqs': (B,max_nobj,3), 'action_seqs': (B,4)}
+    _sync=False (r05, the contract dynamics() has): enqueue only; `_overflow_flag` (int32 device tensor, zeroed by the caller)
+    receives the largest edge count seen if a graph exceeded max_nR - the caller raises Exception("Exceeds max dims") when it reads
+    its results (physics_param_optimizer.dynamics_error_sweep evaluates a whole population / sweep that way).  Pass CPU-resident
+    actions and physics parameters to keep the call free of read-backs."""
     task = ppm_optimizer.task_config
     dev = _require_gpu(device)
     B = state_init.shape[0]
@@ -232,5 +237,6 @@ def dynamics_masked(state_init, state_mask, action, model, device, ppm_optimizer
     state0 = state_init.detach().to(dev, torch.float32).contiguous()
     N_o = state0.shape[1]
     mask_u8 = state_mask.detach().to(dev).to(torch.bool).contiguous().view(torch.uint8)
-    out = _run(model, dev, task, ppm_optimizer, physics_param, B, 1, N_o, 1, state0, mask_u8, xz, delta, repeat)
+    out = _run(model, dev, task, ppm_optimizer, physics_param, B, 1, N_o, 1, state0, mask_u8, xz, delta, repeat,
+               sync=_sync, overflow_flag=_overflow_flag)
     return {"state_seqs": out[:, 0], "action_seqs": decoded[:, 0].to(action.device)}

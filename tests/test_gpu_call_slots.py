@@ -268,3 +268,30 @@ def test_rollout_work_is_what_the_rollout_then_executes(ag, O, dev):
     assert (first == 0).any() and (first > 1).any()
     small = ag.rollout_work(s0, a[:32], m, dev, ppm)                      # below the automatic threshold (64 candidates): no sharing
     assert np.array_equal(small, reps[:32].sum(1))
+
+
+def test_dynamics_error_sweep_equals_sequential_calls(ag, dev):
+    """SURVEY 8(f) rank 4.  dynamics_error_sweep: the objective of the physics-parameter optimiser (reference
+    src/planning/physics_param_optimizer.py:178-226) for a list of parameters, evaluations dealt to streams without waiting
+    (dynamics_masked(_sync=False)) - bit-equal to calling dynamics_error once per parameter, against the reference's recorded
+    values, and "Exceeds max dims" still surfaces."""
+    from helpers import load_golden, task_of
+    from test_gpu_parity import _model as golden_model
+    g = load_golden("ppm_dynamics_error")
+    task = task_of(g)
+    m = golden_model(ag, g, "rope", dev)
+    ppm = _ppm(task, "rope")
+    ppm.model, ppm.device = m, dev
+    n = int(g["n_act"])
+    inits, reals, acts = ([g[f"{k}{i}"] for i in range(n)] for k in ("init", "real", "act"))
+    vals = [[float(v)] for v in g["phys_values"]] * 3
+    one = np.asarray([ag.dynamics_error(v, ppm, inits, reals, acts) for v in vals], np.float64)
+    for streams in (1, 4):
+        got = ag.dynamics_error_sweep(vals, ppm, inits, reals, acts, streams=streams)
+        assert got.dtype == np.float64 and np.array_equal(got, one), streams
+    assert np.abs(one[:len(g["errors"])] - g["errors"]).max() < 2e-5
+    tight = _ppm(dict(task, max_nR=50), "rope")
+    tight.model, tight.device = m, dev
+    with pytest.raises(Exception, match="Exceeds max dims"):
+        ag.dynamics_error_sweep(vals[:3], tight, inits, reals, acts)
+    assert np.array_equal(ag.dynamics_error_sweep(vals, ppm, inits, reals, acts), one)

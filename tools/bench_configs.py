@@ -192,8 +192,57 @@ def mixed(total, steps, reps, report=True):
     return out
 
 
+def ppm_sweep(n_points=50, n_inter=20, reps=3):
+    """the physics-parameter optimiser's inner loop (physics_param_optimizer.py:75-122, 178-226) - the objective
+    dynamics_error evaluated at 50 physics parameters over 20 past interactions (masked rope clouds of 120..200 particles, pushes
+    of the shipped length range).  Sequential calls (what gp_minimize issues: each proposal depends on the last value) against
+    dynamics_error_sweep (a CMA-ES population / a sweep: independent evaluations dealt to streams, one read-back)."""
+    rng = np.random.default_rng(5)
+    mat = "rope"
+    t = np.linspace(0, 1, 200)
+    p = np.stack([-3.5 + 2.5 * t, 0 * t, 1.0 + 0.5 * np.sin(6 * t)], 1)
+    full = (p + rng.normal(0, 0.01, p.shape)).astype(np.float32)
+    task = task_of(mat, 200)
+    task["max_nobj"] = 200
+    m = model_of(mat)
+    ppm = ppm_of(task, mat)
+    ppm.model, ppm.device = m, dev
+    inits, reals, acts = [], [], []
+    for i in range(n_inter):
+        n = int(rng.integers(120, 201))
+        keep = np.sort(rng.choice(200, n, replace=False))
+        inits.append(full[keep])
+        reals.append((full[keep] + rng.normal(0, 0.02, (n, 3)) + np.float32([0.05, 0, 0.03])).astype(np.float32))
+        a = B.make_actions(1, 1, int(rng.integers(5, 15)), full, rng)[0, 0]
+        acts.append(a)
+    params = [[float(v)] for v in np.linspace(-0.2, 1.2, n_points)]
+    seq = lambda: [ag.dynamics_error(v, ppm, inits, reals, acts) for v in params]
+    swp = lambda: ag.dynamics_error_sweep(params, ppm, inits, reals, acts)
+    a0, a1 = np.asarray(seq(), np.float64), swp()
+    assert np.array_equal(a0, a1), float(np.abs(a0 - a1).max())
+    out = {"config": f"rope, dynamics_error over {n_points} physics parameters x {n_inter} masked interactions (120..200 of 200 particles, "
+                     f"repeats 5..14)", "bit_equal": True}
+    for label, fn in (("sequential", seq), ("sweep", swp)):
+        dt = timed(fn, reps)
+        out[f"ms_per_evaluation_{label}"] = dt * 1e3 / n_points
+    for s_ in (1, 2):
+        dt = timed(lambda: ag.dynamics_error_sweep(params, ppm, inits, reals, acts, streams=s_), reps)
+        out[f"ms_per_evaluation_sweep_{s_}_stream{'s' if s_ > 1 else ''}"] = dt * 1e3 / n_points
+    out["speedup_sweep_vs_sequential"] = out["ms_per_evaluation_sequential"] / out["ms_per_evaluation_sweep"]
+    # kernel share of one evaluation (HIP events, one stream)
+    eng = m.engine(dev)
+    eng.reset_stats(); eng.set_profiling(FAMILIES)
+    ag.dynamics_error(params[0], ppm, inits, reals, acts); torch.cuda.synchronize()
+    fam = {f: eng.kernel_stats(f) for f in FAMILIES}
+    eng.set_profiling([]); eng.reset_stats()
+    out["kernel_ms_one_evaluation"] = {f: round(v[0], 4) for f, v in fam.items() if v[1]}
+    out["launches_one_evaluation"] = {f: v[1] for f, v in fam.items() if v[1]}
+    out["kernel_ms_total_one_evaluation"] = sum(v[0] for v in fam.values())
+    return out
+
+
 CONFIGS = {"rope1": lambda: homogeneous("rope", 1, 1, 10, 20), "rope64": lambda: homogeneous("rope", 64, 2, 10, 10),
-           "granular": lambda: homogeneous("granular", 256, 2, 10, 3), "mixed": lambda: mixed(512, 20, 3)}
+           "granular": lambda: homogeneous("granular", 256, 2, 10, 3), "mixed": lambda: mixed(512, 20, 3), "ppm": ppm_sweep}
 
 if __name__ == "__main__":
     import argparse
