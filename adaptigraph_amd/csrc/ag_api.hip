@@ -994,7 +994,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         if (c->n_streams == 2 && (p->B + full - 1) / full >= 8) ns = 4;
     }
     if ((long)p->B * N < c->opt.stream_min_rows) ns = 1;   // small batches are dispatch-bound: a second stream only doubles the launches
-                                          // (rope 64 x 301: 10.8 ms on one stream, 12.9 ms on two)
+                                          // (rope 64 x 301 rows x 20 steps: 9.99 ms on one stream, 11.3 on two; 128 x 301: 14.2 / 13.4)
     // a caller that pipelines independent calls over several streams (the planner's chunk loop) already fills the chip across
     // calls: no fork inside a call that starts while a call of another stream is still running
     if (ns > 1 && !capturing && c->opt.pipeline_fork == 0 && other_slot_busy(c, &sl)) ns = 1;

@@ -92,7 +92,9 @@ struct Options {
                               //                     not touched the object yet follow ONE tool-free base rollout (-1: batches of >= 64
                               //                     candidates and >= 32768 rows, 0 never, 1 whenever possible).  Waits once per call
                               //                     for the contact plan (the GPU is busy with the base rollout meanwhile)
-    int stream_min_rows = 65536;  // [AG_STREAM_MIN_ROWS] batches below this many rows (candidates x particles) stay on the caller's stream
+    int stream_min_rows = 32768;  // [AG_STREAM_MIN_ROWS] batches below this many rows (candidates x particles) stay on the caller's stream
+                              //                     (r05 A/B, rope x 20 steps: 64 x 301 rows 9.99 ms on one stream / 11.3 on two,
+                              //                     128 x 301 rows 14.2 / 13.4: the break-even lies between 19k and 38k rows)
     int pipeline_fork = 0;    // [AG_PIPELINE_FORK]  1: a call forks onto in-library streams even while a call issued on ANOTHER caller
                               //                     stream is still running (0: such a call stays on its stream - the caller is
                               //                     already spreading independent calls over streams, adaptigraph_amd/planner.py)

@@ -802,11 +802,16 @@ __device__ __forceinline__ void mma_b3(const float* wl, const bf16x8* bh, const 
     for (int it = 0; it < NK * MB; ++it) {
         const int ks = it / MB, mb = it % MB;
         bf16x8 nh = ah, nm = am, nl = al;
+#ifndef AG_B3_NOLDS
         if (it + 1 < NK * MB) {
             nh = w[((it + 1) * 3 + 0) * 64 + lane];
             nm = w[((it + 1) * 3 + 1) * 64 + lane];
             nl = w[((it + 1) * 3 + 2) * 64 + lane];
         }
+#else   // timing-only experiment (wrong results): one weight read per k-step; the other m-blocks' pieces are made from it by
+        // one opaque register move each, so that the MFMAs stay distinct but LDS delivers a fifth of the bytes
+        asm volatile("" : "+v"(nh), "+v"(nm), "+v"(nl));
+#endif
         __builtin_amdgcn_sched_barrier(0);
         f32x16 c = acc[mb];
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], c, 0, 0, 0);
@@ -866,7 +871,12 @@ template <int KIND, int G, class Body>
 __device__ __forceinline__ void unit(float* lds, const float* __restrict__ W, int tid, Body body) {
     constexpr int NU = UnitCount<KIND>::N;
     // the other slot held unit G-1: every wavefront finished it before the barrier that ended that unit
-    if (G + 1 < NU) dma_unit(lds + ((G + 1) % NSLOT) * UNIT_FLOATS, W + unit_of<KIND>(G + 1) * UNIT_FLOATS, tid);
+#ifdef AG_B3_NODMA   // timing-only experiment (wrong results): only the first two units are streamed, the ring is then re-used as it is
+    if (G + 1 < 2)
+#else
+    if (G + 1 < NU)
+#endif
+        dma_unit(lds + ((G + 1) % NSLOT) * UNIT_FLOATS, W + unit_of<KIND>(G + 1) * UNIT_FLOATS, tid);
     body(lds + (G % NSLOT) * UNIT_FLOATS);
     if (G + 1 < NU) __syncthreads();                           // waits for this unit's DMA, then publishes it
 }

@@ -162,7 +162,7 @@ int ag_ctx_set_chunk(ag_ctx* ctx, int32_t candidates_per_chunk);
  *                                         WAITS once for the contact plan (the GPU is running the base rollout meanwhile), so
  *                                         ag_rollout_async / ag_rollout_actions are then not purely asynchronous
  *   "stream_min_rows" [AG_STREAM_MIN_ROWS] batches below this many rows (candidates x particles) stay on the caller's stream
- *                                         (default 65536: small batches are dispatch-bound, a second stream only doubles the launches)
+ *                                         (default 32768: small batches are dispatch-bound, a second stream only doubles the launches)
  *   "pipeline_fork"  [AG_PIPELINE_FORK]   0 (default): a call that starts while a call issued on ANOTHER caller stream is still running
  *                                         does not fork onto in-library streams (the caller is already spreading independent calls
  *                                         over streams); 1: it forks as usual
