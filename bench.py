@@ -477,12 +477,15 @@ def main():
     torch.manual_seed(1234)                                        # identical samples on every rank
     ms_mpc = None
     if not args.no_mpc_iter:
-        ag.mpc_iteration(state0, act0, roll_fn, eval_fn, lo_lim, hi_lim, B, dev, group=True if dist_on else None)
+        # (reuse_best_rollout: the best candidate's rollout is taken out of the batch instead of being re-rolled with a batch of
+        # one - exact on this engine, and what Planner does by default for the engine's own dynamics(); single rank only)
+        ag.mpc_iteration(state0, act0, roll_fn, eval_fn, lo_lim, hi_lim, B, dev, group=True if dist_on else None, reuse_best_rollout=True)
         sync_all()
         t0 = time.perf_counter()
         n_mpc = 2
         for _ in range(n_mpc):
-            mpc = ag.mpc_iteration(state0, act0, roll_fn, eval_fn, lo_lim, hi_lim, B, dev, group=True if dist_on else None)
+            mpc = ag.mpc_iteration(state0, act0, roll_fn, eval_fn, lo_lim, hi_lim, B, dev, group=True if dist_on else None,
+                                   reuse_best_rollout=True)
         sync_all()
         tm = torch.tensor([(time.perf_counter() - t0) / n_mpc], device=dev, dtype=torch.float64)
         if dist_on:
@@ -519,10 +522,10 @@ def main():
             return tj["hbm_bytes_per_launch"] if abs(tj[key] - want) <= 0.01 * want else None
 
         def latest(stem):                                   # the newest round's committed measurement of that name
-            for r in ("r04", "r03"):
+            for r in ("r05", "r04", "r03"):
                 if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_{stem}")):
                     return f"{r}_{stem}"
-            return f"r04_{stem}"
+            return f"r05_{stem}"
         traffic_file = latest("traffic_k_edge_enc.json")
         traffic = pmc_traffic(traffic_file, "edges_per_launch", edges_per_launch)
         achieved = FLOP_PER_EDGE * edges_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
@@ -629,7 +632,8 @@ def main():
                     "fp32_equivalent_tflops": b3_tf / 6,
                     "second_kernel": {"kernel": "k_node_prop_b3<false>", "avg_launch_ms": np3_ms, "achieved": np3_tf,
                                       "frac": np3_tf / PEAK_BF16_MFMA_TFLOPS},
-                    "note": "secondary object; PMC MFMA-busy and the clock under this load: profiles/r04_bf16x3_*.json"}
+                    "note": "secondary object; PMC MFMA-busy: profiles/r05_bf16x3_*.json; what bounds it (weight delivery "
+                            "through the LDS, not VALU issue): profiles/r05_bf16x3_limiter.json"}
         if not dist_on and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity_check"] = cpu_baseline(cloud, task, Wt, actions.numpy(), picks, timed_seqs, ref)
         print(json.dumps(line))

@@ -3,7 +3,7 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUNDS = ("r04", "r03")                                       # bench.py takes the newest round's file of a name
+ROUNDS = ("r05", "r04", "r03")                                       # bench.py takes the newest round's file of a name
 
 
 def _latest(stem):
@@ -29,6 +29,15 @@ def test_bench_default_profile_is_a_bench_line():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["roofline"]["traffic"] and d["parity_check"]["ok"]
+    if "candidate_forwards_executed" in d["end_to_end"]:          # r05 accounting: recomputable from the line alone
+        e = d["end_to_end"]
+        flop = e["flop_per_step_executed"] * e["candidate_forwards_executed"] - e["edges_not_encoded_thanks_to_the_shared_first_forward"] * d["roofline"]["flop_per_edge"]
+        assert abs(flop - e["flop_per_call_executed"]) <= 1e-6 * flop
+        assert abs(e["executed_tflops"] - flop / (d["ms_per_step"] * 1e-3) / 1e12) <= 1e-6 * e["executed_tflops"]
+        assert e["candidate_forwards_needed"] == d["config"]["candidates"] * d["config"]["horizon"]
+        v = d["parity_check"]["vs_reference"]
+        assert v["n_candidates"] >= 60 and v["ok"] and all(f["near_tie_in_the_reference"] for f in v["flips_vs_reference"])
+        assert all(f["checker_induced"] is not None for f in d["parity_check"]["edge_flips"])
     # the names bench.py looks up must be the files that are committed
     src = open(os.path.join(ROOT, "bench.py")).read()
     for stem in ("traffic_k_edge_enc.json", "traffic_k_node_prop.json"):

@@ -57,6 +57,19 @@ json.dump({"what": "bench.py --gpus 1 --steps 5 --warmup 2 with AG_BENCH_FORCE_D
            "reward_vectors_bit_equal": one["reward_sha256"] == plain["reward_sha256"]},
           open(os.path.join(P, f"{rnd}_one_rank_rccl.json"), "w"), indent=1)
 shutil.copy(os.path.join(F, "small_call_latency.json"), os.path.join(P, f"{rnd}_small_call_latency.json"))
+for name in ("planner_phases.jsonl", "planner_loop_host.jsonl"):
+    if os.path.exists(os.path.join(F, name)) and os.path.getsize(os.path.join(F, name)):
+        shutil.copy(os.path.join(F, name), os.path.join(P, f"{rnd}_{name}"))
+ws = {}
+for tag in ("1rank", "2ranks"):
+    pth = os.path.join(F, f"work_shards_{tag}.json")
+    rows = [l for l in open(pth) if l.startswith("{")] if os.path.exists(pth) else []
+    if rows:
+        ws[tag] = json.loads(rows[-1])
+if ws:
+    json.dump({"what": "tools/two_rank_planner_shards.py: 4000 pushes of the shipped rope sampler sharded by WORK (adaptigraph_amd.rollout_work) "
+                       "and by count, one rank and two ranks on one GPU (gloo); reward hashes must agree", **ws},
+              open(os.path.join(P, f"{rnd}_work_shards.json"), "w"), indent=1)
 # per-config evidence (tools/profile_configs.sh)
 shutil.copy(os.path.join(C, "other_configs.jsonl"), os.path.join(P, f"{rnd}_other_configs.jsonl"))
 for c in ("rope64", "granular", "mixed"):

@@ -42,7 +42,13 @@ out={n:{c:sum(v)/len(v) for c,v in cs.items()} for n,cs in acc.items()}
 json.dump(out,open(f"{O}/pmc_summary.json","w"),indent=1)
 for n,cs in out.items(): print(n,{c:round(v) for c,v in cs.items()})
 PY
-timeout -k 10 400 python tools/bench_planner.py > $O/planner_configs.jsonl 2> $O/planner_configs.err
+timeout -k 10 600 python tools/bench_planner.py --sorts 1 > $O/planner_configs.jsonl 2> $O/planner_configs.err
+timeout -k 10 300 python tools/bench_planner.py --modes chunked --sorts 0 >> $O/planner_configs.jsonl 2>> $O/planner_configs.err
+timeout -k 10 300 python tools/probe_planner_phases.py > $O/planner_phases.jsonl 2> $O/planner_phases.err || true
+timeout -k 10 300 python tools/probe_loop_host.py rope,granular,cloth > $O/planner_loop_host.jsonl 2> $O/planner_loop_host.err || true
+# work-balanced shards of the planner workload: one rank, then two ranks on this one GPU (gloo)
+AG_SHARD_CANDIDATES=4000 timeout -k 10 300 python tools/two_rank_planner_shards.py > $O/work_shards_1rank.json 2> $O/work_shards.err || true
+AG_SHARD_CANDIDATES=4000 AG_BENCH_SHARE_GPU=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 tools/two_rank_planner_shards.py > $O/work_shards_2ranks.json 2>> $O/work_shards.err || true
 AG_SHARE_PREFIX=0 timeout -k 10 300 python tools/bench_planner.py --modes chunked --sorts 1 > $O/planner_configs_share0.jsonl 2> $O/planner_configs_share0.err
 AG_SHARE_PREFIX=0 AG_SHARE_FIRST=0 timeout -k 10 300 python tools/bench_planner.py --modes chunked --sorts 1 > $O/planner_configs_share00.jsonl 2> $O/planner_configs_share00.err
 # the RCCL calls with a world of one rank (bench.py AG_BENCH_FORCE_DIST=1): reward hash equal to the plain line's
