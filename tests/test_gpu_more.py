@@ -612,8 +612,8 @@ except RuntimeError as e:
     assert "injected failure" in str(e), e
 torch.cuda.synchronize()                                                # nothing of the failed call is left in flight
 # the failed context itself must be usable: it is driven again with a batch of one chunk (chunk 1 is never reached)
-one = ag.dynamics(s0, a[:40], bad, dev, _ppm(task, "cloth"))["state_seqs"]
-assert torch.equal(one, good[:40])
+one = ag.dynamics(s0, a[:16], bad, dev, _ppm(task, "cloth"))["state_seqs"]   # (16 x 1601 rows: below the two-stream threshold)
+assert torch.equal(one, good[:16])
 again = ag.dynamics(s0, a, m, dev, _ppm(task, "cloth"))["state_seqs"]  # and the other context of the process is unaffected
 assert torch.equal(again, good)
 print("CHILD_OK")
