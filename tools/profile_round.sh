@@ -56,7 +56,9 @@ AG_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --gpus 1 --steps 5 --war
 timeout -k 10 300 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-bf16x3 --no-mpc-iter --no-kernel-profile > $O/bench_plain_short.json 2> $O/bench_plain_short.err
 timeout -k 10 120 python tools/trace_mpc_iter.py > $O/small_call_latency.json 2> /dev/null
 cd $R
-bash tools/profile_configs.sh > $O/profile_configs.log 2>&1 || tail -20 $O/profile_configs.log
+# (SKIP_CONFIGS=1: the per-config evidence is then run as a call of its own - gpurun -- 'bash tools/profile_configs.sh' - the two
+# together can exceed one call's time limit)
+[ "${SKIP_CONFIGS:-0}" = 1 ] || bash tools/profile_configs.sh > $O/profile_configs.log 2>&1 || tail -20 $O/profile_configs.log
 find $O -type f \( -name '*kernel_trace*' -o -name '*.db' -o -name '*agent_info*' -o -name '*counter_collection*' \) -delete
 du -sh $O
 cat $O/bench_default.json | cut -c1-400
