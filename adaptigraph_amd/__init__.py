@@ -5,6 +5,15 @@
 
 Hand-written HIP kernels (adaptigraph_amd/csrc) behind a C-ABI (include/adaptigraph_amd.h).  No CPU fallback.
 """
+import os as _os
+
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise.
+# The engine runs a large batch on four in-library streams, the planner deals its chunk loop to six, torch.distributed's RCCL
+# brings one more: eight queues unless the user chose otherwise.  Read by the HIP runtime when it initialises - a process that
+# has already touched the GPU keeps what it had (DESIGN.md section 6; measured: 474.8 -> 467.5 ms per bench step beside an RCCL
+# group, planner call rope 165 -> 151 ms).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .context import Engine, default_engine
 from .forward_dynamics import dynamics, dynamics_masked, rollout_work
 from .graph import (EdgeList, construct_edges_from_states_batch, construct_edges_from_states, construct_edges_index,

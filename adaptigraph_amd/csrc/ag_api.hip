@@ -93,7 +93,7 @@ struct ag_ctx {
     int chunk = 0;
     Options opt;                 // per-context switches: environment defaults read once at create, ag_ctx_set_option afterwards
     void* diag = nullptr;        // diagnostic build only: probe state of this context (ag_diag.hip)
-    static constexpr int kMaxSlots = 4;
+    static constexpr int kMaxSlots = 8;
     static constexpr int kMaxStreams = CallSlot::kMaxStreams;
     CallSlot slots[kMaxSlots];
     unsigned long long slot_tick = 0;

@@ -21,7 +21,7 @@ arithmetic of the hot path.  What is new:
 * The reference's own loop - 40 x `trajectory_optimization`, then `merge_res` - is served as it stands (r05): when
   `model_rollout_fn` is the engine's `dynamics` behind a `functools.partial` (what plan.py:190 builds), consecutive calls on
   the same `state_cur` / `act_seq` tensors are independent of each other, and the class deals them to `pipeline_chunks` (default
-  4) side streams: each call's sampling, rollout, evaluation and update are enqueued on one of them without waiting for the GPU
+  6) side streams: each call's sampling, rollout, evaluation and update are enqueued on one of them without waiting for the GPU
   (the rollout's "Exceeds max dims" flag comes back through pinned memory), the caller's stream is made to wait (on the GPU) for
   the call's end before the result is handed back - so results are used in stream order as always - and the next call starts on
   another stream while this one still runs.  Same samples (the generator advances on the host, in call order), same per-candidate
@@ -153,7 +153,9 @@ class Planner(object):
         self.reuse_best_rollout = bool(config.get("reuse_best_rollout", self._eng_rollout is not None))
         # Side streams the independent calls of the caller's chunk loop are dealt to (module docstring); 0 / 1: every call on
         # the caller's stream, waiting for its rollout's flags (the strict per-call error behaviour).
-        self.pipeline_chunks = int(config.get("pipeline_chunks", 4 if self._eng_rollout is not None else 0))
+        # (6: measured on the shipped 40 x 500 configuration, tools/probe_loop_host.py - rope 161 / 151 / 159 ms per planner call
+        # with 4 / 6 / 8 streams and eight hardware queues, granular 241 / 225 / 227, cloth 212 / 217 / 219)
+        self.pipeline_chunks = int(config.get("pipeline_chunks", 6 if self._eng_rollout is not None else 0))
         self._side = None            # (device, [streams])
         self._pipe_in = None         # (state_cur, act_seq, (versions, caller stream), entry event): inputs of the running series
         self._pipe_i = 0

@@ -21,7 +21,7 @@
  *     ctx workspace (grown monotonically, freed by ag_ctx_destroy).
  *   - One ctx per (process, device); a ctx is not re-entrant (one host thread at a time).  Calls on ONE stream are ordered by
  *     the stream.  Calls issued on DIFFERENT streams run side by side: the launch plan, the repeat table, the workspace and the
- *     pinned read-back buffers of a call belong to a per-stream "call slot" (up to 4 per ctx; r05).  A fifth stream takes over the
+ *     pinned read-back buffers of a call belong to a per-stream "call slot" (up to 8 per ctx; r05).  A ninth stream takes over the
  *     least recently used slot and first waits (GPU side, an event) for that slot's last call.  That is what lets a caller deal
  *     the 40 independent dynamics() calls of the planner's chunk loop (plan.py:241-247) to a few streams
  *     (adaptigraph_amd/planner.py).  Early returns before any work was enqueued (argument errors) record nothing.  A call that is

@@ -39,10 +39,10 @@ def O():
 LIMITS = dict(action_lower_lim=[-4.5, -2.5, -3.14, 0.0], action_upper_lim=[0.0, 4.5, 3.14, 6.0])
 
 
-def test_calls_on_seven_streams_of_one_context_equal_the_synchronous_results(ag, O, dev):
-    """More caller streams than call slots (4): a stream that finds none free takes over the least recently used one after that
+def test_calls_on_eleven_streams_of_one_context_equal_the_synchronous_results(ag, O, dev):
+    """More caller streams than call slots (8): a stream that finds none free takes over the least recently used one after that
     slot's last call.  Asynchronous calls of three shapes - small (no sharing), prefix-sharing with the base rollout kept in the
-    context and read by calls on OTHER streams, masked-free host-decoded - round-robin over seven streams, nothing waited for in
+    context and read by calls on OTHER streams, masked-free host-decoded - round-robin over eleven streams, nothing waited for in
     between: every result equals the synchronous call's."""
     rng = np.random.default_rng(503)
     W, m = _model(ag, O, "rope", 503, dev)
@@ -50,7 +50,7 @@ def test_calls_on_seven_streams_of_one_context_equal_the_synchronous_results(ag,
     t_dev = _task("rope", max_nR=40000, **LIMITS)
     t_host = _task("rope", max_nR=40000)
     jobs = []
-    for i in range(21):
+    for i in range(33):
         cloud = big if i % 3 == 1 else small
         B = 96 if i % 3 == 1 else (40 if i % 3 == 0 else 130)
         a = torch.from_numpy(_actions(cloud, B, 1, rng.integers(1, 6, (B, 1)), rng, spread=2.5))
@@ -58,11 +58,11 @@ def test_calls_on_seven_streams_of_one_context_equal_the_synchronous_results(ag,
         jobs.append((torch.from_numpy(cloud).to(dev), a.to(dev) if task is t_dev else a, _ppm(task, "rope")))
     want = [ag.dynamics(s, a, m, dev, p)["state_seqs"].clone() for s, a, p in jobs]
     torch.cuda.synchronize()
-    streams = [torch.cuda.Stream(device=dev) for _ in range(7)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(11)]
     flags = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in jobs]
     got = []
     for i, (s, a, p) in enumerate(jobs):
-        with torch.cuda.stream(streams[i % 7]):
+        with torch.cuda.stream(streams[i % 11]):
             got.append(ag.dynamics(s, a, m, dev, p, _sync=False, _overflow_flag=flags[i])["state_seqs"])
     torch.cuda.synchronize()
     for i in range(len(jobs)):
@@ -132,7 +132,7 @@ def _loop(planner, s0, act_seq, n_chunk):
 
 def test_planner_loop_dealt_to_streams_equals_the_strict_loop_bitwise(ag, O, dev):
     """The drop-in as plan.py drives it: `model_rollout_fn = partial(dynamics, model=..., device=..., ppm_optimizer=...)`, 12 x
-    trajectory_optimization + merge_res.  Default (calls dealt to 4 streams, no waiting, winners' rollouts taken out of their
+    trajectory_optimization + merge_res.  Default (calls dealt to 6 streams, no waiting, winners' rollouts taken out of their
     batches) against the strict execution (one stream, every call waits for its flags, winners re-rolled with a batch of one):
     same winner, same rollout, same reward, same per-chunk results, same generator state - bit for bit; 130 x 601 rows, so the
     contact-free prefix and the kept base rollout are in play too."""
@@ -144,11 +144,11 @@ def test_planner_loop_dealt_to_streams_equals_the_strict_loop_bitwise(ag, O, dev
     ppm = _ppm(task, "rope")
     S, n_chunk, H = 130, 12, 1
     planner, lo, hi = _planner(ag, m, ppm, dev, cloud, S, H, task)
-    assert planner.pipeline_chunks == 4 and planner.reuse_best_rollout       # the defaults for the engine's own dynamics()
+    assert planner.pipeline_chunks == 6 and planner.reuse_best_rollout       # the defaults for the engine's own dynamics()
     torch.manual_seed(3)
     act_seq = torch.rand((H, 4), device=dev) * (hi - lo) + lo
     results = {}
-    for label, pipe, reuse in (("default", 4, True), ("strict", 0, False), ("two streams, re-rolled", 2, False), ("one stream, reuse", 0, True)):
+    for label, pipe, reuse in (("default", 6, True), ("strict", 0, False), ("two streams, re-rolled", 2, False), ("one stream, reuse", 0, True)):
         planner.pipeline_chunks, planner.reuse_best_rollout = pipe, reuse
         torch.manual_seed(4)
         merged, per_chunk = _loop(planner, s0, act_seq, n_chunk)
@@ -166,7 +166,7 @@ def test_planner_loop_dealt_to_streams_equals_the_strict_loop_bitwise(ag, O, dev
             assert torch.equal(per_chunk[ci]["best_model_output"]["state_seqs"], ref[1][ci]["best_model_output"]["state_seqs"]), (label, ci)
             assert torch.equal(per_chunk[ci]["best_eval_output"]["reward_seqs"], ref[1][ci]["best_eval_output"]["reward_seqs"]), (label, ci)
     # and the chunked entry (one rollout call for all chunks) gives the same
-    planner.pipeline_chunks, planner.reuse_best_rollout = 4, True
+    planner.pipeline_chunks, planner.reuse_best_rollout = 6, True
     torch.manual_seed(4)
     fused = planner.trajectory_optimization_chunked(s0, act_seq, n_chunk)
     assert torch.equal(fused["act_seq"], ref[0]["act_seq"])

@@ -101,13 +101,13 @@ def main():
             return run
         loop_fn = lambda: loop_call(planner, s0, act_seq, n_chunk)
         chunked_fn = lambda: planner.trajectory_optimization_chunked(s0, act_seq, n_chunk)
-        # loop / chunked: the class as a drop-in gets it (r05: independent calls dealt to 4 streams, winners' rollouts taken out of
+        # loop / chunked: the class as a drop-in gets it (r05: independent calls dealt to 6 streams, winners' rollouts taken out of
         # their batches).  loop_r04: one stream, every call waits for its flags, winners re-rolled with a batch of one (the r04
         # behaviour).  loop_nopipe / loop_reroll: one of the two r05 changes each.  chunked_reroll: winners re-rolled (one call).
-        for mode, fn in (("loop", variant(loop_fn, 4, True)), ("chunked", variant(chunked_fn, 4, True)),
+        for mode, fn in (("loop", variant(loop_fn, 6, True)), ("chunked", variant(chunked_fn, 6, True)),
                          ("loop_r04", variant(loop_fn, 0, False)), ("loop_nopipe", variant(loop_fn, 0, True)),
-                         ("loop_reroll", variant(loop_fn, 4, False)), ("loop_2streams", variant(loop_fn, 2, True)),
-                         ("loop_3streams", variant(loop_fn, 3, True)), ("chunked_reroll", variant(chunked_fn, 4, False))):
+                         ("loop_reroll", variant(loop_fn, 6, False)), ("loop_2streams", variant(loop_fn, 2, True)),
+                         ("loop_4streams", variant(loop_fn, 4, True)), ("chunked_reroll", variant(chunked_fn, 6, False))):
             if mode not in args.modes.split(","):
                 continue
             for sort in [int(x) for x in args.sorts.split(",")]:

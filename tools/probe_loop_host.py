@@ -19,8 +19,8 @@ def main():
         eng = m.engine(dev)
         torch.manual_seed(0)
         act_seq = torch.rand((1, 4), device=dev) * (hi - lo) + lo
-        for label, pipe, reuse, opts in (("default", 4, True, {}), ("streams=1", 4, True, {"streams": 1}),
-                                         ("pipeline_fork=1", 4, True, {"pipeline_fork": 1}),
+        for label, pipe, reuse, opts in (("default", 6, True, {}), ("4 side streams", 4, True, {}), ("8 side streams", 8, True, {}), ("streams=1", 6, True, {"streams": 1}),
+                                         ("pipeline_fork=1", 6, True, {"pipeline_fork": 1}),
                                          ("one stream, no wait (pipeline 1)", 1, True, {}), ("r04", 0, False, {})):
             planner.pipeline_chunks, planner.reuse_best_rollout = pipe, reuse
             with eng.options(**opts):
