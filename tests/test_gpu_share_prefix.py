@@ -303,10 +303,11 @@ def test_a_device_planned_call_can_be_captured_in_a_hip_graph(ag, O, dev):
             torch.cuda.synchronize()
 
 
-def test_rollout_calls_on_different_streams_of_one_context_are_serialised(ag, O, dev):
-    """The workspace and the plans are per-context: an asynchronous call on another stream than the previous one waits for it
-    (include/adaptigraph_amd.h).  Back-to-back asynchronous calls alternating between two streams, no synchronisation in between:
-    every result equals the synchronous one."""
+def test_rollout_calls_alternating_between_two_streams_equal_the_synchronous_results(ag, O, dev):
+    """The workspace and the plans of a call belong to the call slot of its caller stream (r05; r04 serialised calls of different
+    streams behind an end-of-call event): back-to-back asynchronous calls alternating between two streams, no synchronisation in
+    between, run side by side - every result equals the synchronous one (include/adaptigraph_amd.h; more streams than slots:
+    tests/test_gpu_call_slots.py)."""
     rng = np.random.default_rng(461)
     task = _task("rope", max_nR=40000, action_lower_lim=[-4.5, -2.5, -3.14, 0.0], action_upper_lim=[0.0, 4.5, 3.14, 6.0])
     W, m = _model(ag, O, "rope", 461, dev)
