@@ -24,6 +24,7 @@ hipError_t launch_node_prop_lat(const float* wl, const GraphBufs& g, int round, 
 void* diag_create();
 void diag_destroy(void* diag);
 int diag_fail_at_chunk(void* diag);
+int diag_timing_skip(void* diag);
 #endif
 }
 using namespace ag;
@@ -1440,9 +1441,10 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
         }
     }
 
-    int fail_at = -1;
+    int fail_at = -1, timing_skip = 0;
 #ifdef AG_DIAG   // AG_TEST_FAIL_AT_CHUNK=n (diagnostic build only): fail with AG_ERR_HIP before enqueuing chunk n, as a failed launch would
     fail_at = diag_fail_at_chunk(c->diag);
+    timing_skip = diag_timing_skip(c->diag);         // AG_TIMING_SKIP (diagnostic build only): timing-only, wrong results
 #endif
     // The chunk loop as a callable: whatever it returns, the forked streams are joined back into the caller's stream
     // below, so that a failure in the middle never leaves work of this call in flight on a stream the caller cannot see.
@@ -1536,12 +1538,14 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
                     ea.share_stats = sl.d_share_stats; g.C_share = C_share; g.share_kb = kb;
                     ea.share_start = d_start; ea.share_cand = ra.cand; ea.share_b0 = b0;
                 }
-                HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));
-                if (g.ns_edge && !ell_full) { Scoped s(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, n_live, N, edge_cap, w.ns_edge, w.n_ns, ea.live, cs)); }
+                if (!(timing_skip & 1) || ai == 1) {
+                    HIPCHK(c, launch_edge_build(ea, cs, prof_mark, c));
+                    if (g.ns_edge && !ell_full) { Scoped s(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, n_live, N, edge_cap, w.ns_edge, w.n_ns, ea.live, cs)); }
+                }
                 rc = run_model(c, g, w.r.pred, w.r.motion, cs);
                 if (rc) return rc;
                 ra.ai = ai;
-                { Scoped s(c, FAM_ROLL_UPDATE); HIPCHK(c, launch_roll_update(ra, w.r, g, cs)); }
+                if (!(timing_skip & 2) || ai == max_rep) { Scoped s(c, FAM_ROLL_UPDATE); HIPCHK(c, launch_roll_update(ra, w.r, g, cs)); }
             }
         }
     }

@@ -7,6 +7,9 @@
 //   AG_NODE_PROBE=n   stamp the phases of the first n k_node_prop<false> launches (synchronises!); n < 0: stamp every launch
 //                     without synchronising and report the clock of the last one when the context is destroyed
 //   AG_TEST_FAIL_AT_CHUNK=n   ag_rollout_async fails before enqueuing chunk n, as a failed launch would
+//   AG_TIMING_SKIP=mask       TIMING ONLY, WRONG RESULTS: the rollout's step loop leaves out the edge builder (bit 0; the graph of
+//                             a look-ahead step's first forward is kept) and / or k_roll_update (bit 1; only the capturing step
+//                             runs it) - the upper bound of what fusing those launches into a neighbour could save (r05)
 #ifdef AG_DIAG
 #include "ag_common.h"
 #include <algorithm>
@@ -17,7 +20,7 @@
 namespace ag {
 
 struct Diag {
-    int clock_left = 0, node_left = 0, fail_at_chunk = -1;
+    int clock_left = 0, node_left = 0, fail_at_chunk = -1, timing_skip = 0;
     bool node_tail = false;
     unsigned long long* dbg_e = nullptr; unsigned cap_e = 0;
     unsigned long long* dbg_n = nullptr; unsigned cap_n = 0; unsigned tail_nwg = 0;
@@ -28,9 +31,11 @@ void* diag_create() {
     if (const char* e = getenv("AG_CLOCK_PROBE")) d->clock_left = atoi(e);
     if (const char* e = getenv("AG_NODE_PROBE")) { const int v = atoi(e); d->node_left = v > 0 ? v : 0; d->node_tail = v < 0; }
     if (const char* e = getenv("AG_TEST_FAIL_AT_CHUNK")) d->fail_at_chunk = atoi(e);
+    if (const char* e = getenv("AG_TIMING_SKIP")) d->timing_skip = atoi(e);
     return d;
 }
 int diag_fail_at_chunk(void* v) { return v ? static_cast<Diag*>(v)->fail_at_chunk : -1; }
+int diag_timing_skip(void* v) { return v ? static_cast<Diag*>(v)->timing_skip : 0; }
 
 static double node_clock(const std::vector<unsigned long long>& h, unsigned nwg, int* n_out) {
     double ghz = 0; int n = 0;
