@@ -188,36 +188,27 @@ __device__ __forceinline__ bool pair_within(const EdgeLds& l, int N, float xi, f
     return vj && (__fsub_rn(d, thr2) < 0.0f);              // graph.py:267
 }
 
-// rank counting over keys[0..nb): returns the k-th smallest key; optionally compacts the k smallest to the front.
-__device__ __forceinline__ unsigned long long select_kth(unsigned long long* keys, int nb, int k, bool compact) {
+template <int U>
+__device__ __forceinline__ unsigned long long select_kth_slots(unsigned long long* keys, int nb, int k, bool compact) {
     const int lane = lane_id();
-    if (nb <= 64 && !compact) {                            // common case: one key per lane
-        const unsigned long long mine = lane < nb ? keys[lane] : KEY_INF;
-        int rank = 0;
-        for (int t = 0; t < nb; ++t) rank += keys[t] < mine ? 1 : 0;
-        const unsigned long long bal = __ballot(lane < nb && rank == k - 1);
-        const int src = __ffsll((long long)bal) - 1;
-        const unsigned lo = __shfl((unsigned)(mine & 0xffffffffull), src);
-        const unsigned hi = __shfl((unsigned)(mine >> 32), src);
-        return ((unsigned long long)hi << 32) | lo;
-    }
-    unsigned long long mine[CAP / 64];
-    int rank[CAP / 64];
+    unsigned long long mine[U];
+    int rank[U];
 #pragma unroll
-    for (int u = 0; u < CAP / 64; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int e = lane + 64 * u;
         mine[u] = e < nb ? keys[e] : KEY_INF;
         rank[u] = 0;
     }
+#pragma unroll 4
     for (int t = 0; t < nb; ++t) {
         const unsigned long long other = keys[t];          // same address in every lane: LDS broadcast
 #pragma unroll
-        for (int u = 0; u < CAP / 64; ++u) rank[u] += other < mine[u] ? 1 : 0;
+        for (int u = 0; u < U; ++u) rank[u] += other < mine[u] ? 1 : 0;
     }
     wave_lds_sync();
     unsigned long long kth = 0;
 #pragma unroll
-    for (int u = 0; u < CAP / 64; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int e = lane + 64 * u;
         const bool is_kth = e < nb && rank[u] == k - 1;
         const unsigned long long bal = __ballot(is_kth);
@@ -231,6 +222,29 @@ __device__ __forceinline__ unsigned long long select_kth(unsigned long long* key
     }
     wave_lds_sync();
     return kth;
+}
+
+// rank counting over keys[0..nb): returns the k-th smallest key; optionally compacts the k smallest to the front.
+__device__ __forceinline__ unsigned long long select_kth(unsigned long long* keys, int nb, int k, bool compact) {
+    const int lane = lane_id();
+    if (nb <= 64 && !compact) {                            // common case: one key per lane
+        const unsigned long long mine = lane < nb ? keys[lane] : KEY_INF;
+        int rank = 0;
+        for (int t = 0; t < nb; ++t) rank += keys[t] < mine ? 1 : 0;
+        const unsigned long long bal = __ballot(lane < nb && rank == k - 1);
+        const int src = __ffsll((long long)bal) - 1;
+        const unsigned lo = __shfl((unsigned)(mine & 0xffffffffull), src);
+        const unsigned hi = __shfl((unsigned)(mine >> 32), src);
+        return ((unsigned long long)hi << 32) | lo;
+    }
+    // general case: U = ceil(nb / 64) keys per lane (r05: the loops run over the slots that hold keys - a rope row has 60..120
+    // in-radius senders, i.e. two slots, and paid for four; slots beyond nb hold KEY_INF and never matter)
+    switch ((nb + 63) >> 6) {
+    case 1: return select_kth_slots<1>(keys, nb, k, compact);
+    case 2: return select_kth_slots<2>(keys, nb, k, compact);
+    case 3: return select_kth_slots<3>(keys, nb, k, compact);
+    default: return select_kth_slots<CAP / 64>(keys, nb, k, compact);
+    }
 }
 
 // One receiver row, top-k active.  Collects in-radius senders, applies top-k, writes the kept senders that are not
