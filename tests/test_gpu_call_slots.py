@@ -295,3 +295,36 @@ def test_dynamics_error_sweep_equals_sequential_calls(ag, dev):
     with pytest.raises(Exception, match="Exceeds max dims"):
         ag.dynamics_error_sweep(vals[:3], tight, inits, reals, acts)
     assert np.array_equal(ag.dynamics_error_sweep(vals, ppm, inits, reals, acts), one)
+
+
+def test_dealt_calls_with_changing_start_states_replace_the_kept_base_rollout_safely(ag, O, dev):
+    """An MPC loop that calls trajectory_optimization once per control step hands the planner a NEW start state every time and
+    never calls merge_res.  Each dealt call then recomputes the tool-free base rollout the context keeps (one slot, shared by all
+    call slots) while the previous call - on another stream, reading the previous base rollout - may still be running: the
+    replacing call first makes its stream wait for every other slot's last call.  Ten calls alternating between three start
+    states, nothing waited for in between: every result equals the strict one-stream execution bit for bit."""
+    rng = np.random.default_rng(557)
+    task = _task("rope", max_nR=40000, **LIMITS)
+    W, m = _model(ag, O, "rope", 557, dev)
+    cloud = _rope(600, rng)
+    ppm = _ppm(task, "rope")
+    planner, lo, hi = _planner(ag, m, ppm, dev, cloud, 130, 1, task)
+    states = [torch.from_numpy((cloud + np.float32([0.01 * k, 0, 0.02 * k])).astype(np.float32)).to(dev) for k in range(3)]
+    torch.manual_seed(6)
+    act_seq = torch.rand((1, 4), device=dev) * (hi - lo) + lo
+    order = [0, 1, 2, 0, 0, 1, 2, 2, 1, 0]
+
+    def run(pipe):
+        planner.pipeline_chunks = pipe
+        torch.manual_seed(7)
+        out = [planner.trajectory_optimization(states[k], act_seq) for k in order]
+        torch.cuda.synchronize()
+        planner.check_pending(block=True)
+        return [(r["act_seq"].clone(), r["best_model_output"]["state_seqs"].clone(), r["best_eval_output"]["reward_seqs"].clone()) for r in out]
+
+    strict = run(0)
+    for pipe in (6, 3):
+        got = run(pipe)
+        for i, (a, b) in enumerate(zip(got, strict)):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), (pipe, i)
+    assert not torch.equal(strict[0][1], strict[1][1])                       # the start states do lead to different rollouts
