@@ -53,6 +53,19 @@ def dynamics_error(physics_param, ppm_optimizer, state_init_list, state_real_lis
     return mean_chamfer(rolled["state_seqs"].detach(), after, before_valid, after_valid).mean()
 
 
+_SWEEP_STREAMS = {}
+
+
+def _sweep_streams(device, n):
+    """the same n side streams for every sweep on a device (the engine keeps one call slot per caller stream: fresh streams per
+    sweep would only make it recycle slots)"""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    have = _SWEEP_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device))
+    return have[:n]
+
+
 @torch.no_grad()
 def dynamics_error_sweep(physics_params, ppm_optimizer, state_init_list, state_real_list, actions, streams=4):
     """dynamics_error for a LIST of physics parameters - a CMA-ES population (`es.ask()` of optimize_cma's strategy, :125-175:
@@ -73,7 +86,7 @@ def dynamics_error_sweep(physics_params, ppm_optimizer, state_init_list, state_r
     cur = torch.cuda.current_stream(device)
     entry = torch.cuda.Event()
     entry.record(cur)
-    side = [torch.cuda.Stream(device) for _ in range(max(1, min(int(streams), K)))]
+    side = _sweep_streams(device, max(1, min(int(streams), K)))
     for k, pp in enumerate(physics_params):
         st = side[k % len(side)]
         if k < len(side):
