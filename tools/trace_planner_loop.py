@@ -7,7 +7,11 @@ Planner.trajectory_optimization + merge_res), from a rocprofv3 HIP-API + kernel 
 `run` executes 2 warm planner calls and 1 traced one (mode loop | loop_r04 | loop_nopipe | chunked); `report` cuts the LAST planner call of
 the trace into its iterations at the sampling kernels (k_mppi_sample: one per trajectory_optimization call) and prints, per
 call and per iteration (median / total): wall time, the union of kernel intervals (GPU busy), the idle rest, kernels launched,
-and the time the host spent inside blocking HIP calls.  Diagnostic tool; one GPU."""
+and the time the host spent inside blocking HIP calls.  Diagnostic tool; one GPU.
+Caveat: under rocprofv3 a kernel launch costs the host ~28 us (5-6 us unprofiled), so a loop of small launches becomes launch-bound
+and the side streams of the default (dealt) mode hardly ever hold work at the same time - its trace shows ~1 kernel in flight
+(--kernel-trace alone: 250 ms per call, 143 unprofiled).  The trace is the right tool for the one-stream modes (is the GPU busy or
+idle behind the waits?) and for the chunked entry; the dealt mode is measured unprofiled by tools/probe_loop_host.py."""
 import csv, glob, json, os, sys
 import numpy as np
 
