@@ -20,6 +20,63 @@ import sys
 import time
 import types
 
+
+def _parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--candidates", type=int, default=1024)
+    ap.add_argument("--side", type=int, default=45, help="cloth grid side (45 -> 2025 particles)")
+    ap.add_argument("--lookahead", type=int, default=2)
+    ap.add_argument("--repeat", type=int, default=10)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel family (adds overhead)")
+    ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-bf16x3", action="store_true", help="skip the secondary bf16x3-mode measurement")
+    ap.add_argument("--host-decode", action="store_true", help="decode the actions on the host (ag_rollout) instead of the "
+                    "device-planned path the planner's GPU-resident samples take (ag_rollout_actions)")
+    ap.add_argument("--no-mpc-iter", action="store_true", help="skip the ms/MPC-iteration leg (profiling runs: its B=1 "
+                    "best-candidate rollouts would dilute per-kernel averages)")
+    ap.add_argument("--plumbing-only", default=None, metavar="ok|fail-rank-R",
+                    help="launch check without a GPU (tests/test_bench_launch.py): the ranks meet over gloo, rank 0 prints what "
+                         "every rank saw of the launch, nothing of the engine is imported; fail-rank-R makes rank R exit 3")
+    return ap
+
+
+def launch_command(n_gpus, argv, port):
+    """The command `bench.py --gpus N` starts when no launcher wrapped it: the driver's documented launch line."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks_if_needed(argv):
+    """`python bench.py --gpus N` with N > 1 and NO launcher in front (no RANK / WORLD_SIZE in the environment): this process - which
+    has imported nothing that touches the GPU - starts the N ranks as a CHILD `python -m torch.distributed.run ... bench.py <same
+    args>` (never an exec), lets the child write to this process's stdout / stderr (rank 0's JSON line arrives verbatim) and exits
+    with the child's code, non-zero if any rank failed.  Under an existing launcher (WORLD_SIZE set) it returns and the caller
+    runs as one rank.  Returns None to carry on in this process, else the exit code."""
+    args, _ = _parser().parse_known_args(argv)
+    if args.gpus <= 1 or ("WORLD_SIZE" in os.environ and "RANK" in os.environ):
+        return None
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["AG_BENCH_LAUNCHED_BY"] = "bench.py"
+    cmd = launch_command(args.gpus, argv, port)
+    print("bench.py: --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env, cwd=os.path.dirname(os.path.abspath(__file__))).returncode
+
+
+if __name__ == "__main__":
+    _rc = launch_ranks_if_needed(sys.argv[1:])          # before torch / HIP: the parent of the ranks never initialises the GPU
+    if _rc is not None:
+        sys.exit(_rc)
+
 # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The engine runs a large batch on four
 # streams; torch.distributed adds RCCL's, and with five streams on four queues two of the engine's share one and serialise
 # (measured with a one-rank RCCL group: 474.8 ms per step against 466.2 without the group; with 8 queues 467.5 / 465.7).  Read by
@@ -259,30 +316,43 @@ def cpu_baseline(cloud, task, W, actions, picks, gpu_seqs, ref, tol=1e-5):
     return base, parity
 
 
+def plumbing_only(args, world, rank, local_rank):
+    """--plumbing-only: what the launch gave every rank, gathered over gloo and printed by rank 0 as one JSON line.  No GPU, no
+    engine import: the CPU check of launch_ranks_if_needed (tests/test_bench_launch.py)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "world_env": world, "world_dist": dist.get_world_size(),
+                                      "pid": os.getpid(), "argv": sys.argv[1:]})
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = [{"rank": rank, "local_rank": local_rank, "world_env": world, "world_dist": 1, "pid": os.getpid(), "argv": sys.argv[1:]}]
+    if args.plumbing_only.startswith("fail-rank-") and rank == int(args.plumbing_only.rsplit("-", 1)[1]):
+        sys.exit(3)
+    if rank == 0:
+        print(json.dumps({"plumbing": seen, "n_gpus": world, "launched_by": os.environ.get("AG_BENCH_LAUNCHED_BY", "external launcher")}),
+              flush=True)
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--candidates", type=int, default=1024)
-    ap.add_argument("--side", type=int, default=45, help="cloth grid side (45 -> 2025 particles)")
-    ap.add_argument("--lookahead", type=int, default=2)
-    ap.add_argument("--repeat", type=int, default=10)
-    ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-all", action="store_true", help="HIP-event time every kernel family (adds overhead)")
-    ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-kernel HIP-event pass")
-    ap.add_argument("--no-bf16x3", action="store_true", help="skip the secondary bf16x3-mode measurement")
-    ap.add_argument("--host-decode", action="store_true", help="decode the actions on the host (ag_rollout) instead of the "
-                    "device-planned path the planner's GPU-resident samples take (ag_rollout_actions)")
-    ap.add_argument("--no-mpc-iter", action="store_true", help="skip the ms/MPC-iteration leg (profiling runs: its B=1 "
-                    "best-candidate rollouts would dilute per-kernel averages)")
-    args = ap.parse_args()
+    args = _parser().parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        # the launcher decides how many ranks exist; the line reports what dist sees (n_gpus = world size), never the flag
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: reporting n_gpus={world}",
+              file=sys.stderr, flush=True)
+    if args.plumbing_only:
+        return plumbing_only(args, world, rank, local_rank)
+    n_dev = torch.cuda.device_count()                       # (counting devices does not initialise HIP)
+    if os.environ.get("AG_BENCH_SHARE_GPU") != "1" and local_rank >= n_dev:
+        sys.exit(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) has no GPU of its own: {n_dev} device(s) visible, {world} ranks "
+                 "(one process per GPU; AG_BENCH_SHARE_GPU=1 is the one-GPU rehearsal mode)")
     # Rehearsal hooks (never set by the driver): AG_BENCH_SHARE_GPU=1 maps every rank onto the GPUs that exist (two
     # ranks on a one-GPU box) and AG_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device.
     if os.environ.get("AG_BENCH_SHARE_GPU") == "1":
@@ -403,7 +473,18 @@ def main():
         for _ in range(20):
             dist.all_reduce(two, op=dist.ReduceOp.MAX); _agc(probe, B)
         sync_all()
-        multi = {"per_rank_ms_per_step": [float(t.item()) / args.steps * 1e3 for t in per_rank],
+        props = torch.cuda.get_device_properties(dev)
+        ids = [None] * world
+        if world > 1:
+            dist.all_gather_object(ids, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": dev.index,
+                                         "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None,
+                                         "pid": os.getpid()})
+        else:
+            ids = [{"rank": 0, "local_rank": 0, "device_index": dev.index, "pci_bus_id": getattr(props, "pci_bus_id", None),
+                    "uuid": str(getattr(props, "uuid", "")) or None, "pid": os.getpid()}]
+        multi = {"world_size": dist.get_world_size(), "launched_by": os.environ.get("AG_BENCH_LAUNCHED_BY", "external launcher"),
+                 "ranks": ids, "distinct_devices": len({(i["device_index"], i["uuid"], i["pci_bus_id"]) for i in ids}),
+                 "per_rank_ms_per_step": [float(t.item()) / args.steps * 1e3 for t in per_rank],
                  "exchange_us_per_step": (time.perf_counter() - tc) / 20 * 1e6,
                  "backend": dist.get_backend(), "candidates_per_rank": [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]}
     dt = float(tmax.item())

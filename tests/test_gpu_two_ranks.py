@@ -85,6 +85,24 @@ def test_two_ranks_on_one_gpu_equal_one_rank_bitwise():
     assert mg["candidates_per_rank"] == [32, 32] and len(mg["per_rank_ms_per_step"]) == 2 and mg["exchange_us_per_step"] > 0
 
 
+def test_bare_command_launches_its_own_two_ranks():
+    """`python3 bench.py --gpus 2` with NO launcher in front (the shape of the only command the driver has issued so far): the
+    parent starts torch.distributed.run as a child before anything touches the GPU; one line comes out, n_gpus 2, world size as
+    torch.distributed sees it, same reward bits as one rank.  (CPU plumbing of the same entry: tests/test_bench_launch.py.)"""
+    l1 = _one_rank_line()
+    env2 = dict(_clean_env(), AG_BENCH_SHARE_GPU="1", AG_BENCH_BACKEND="gloo")
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS, env=env2, cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    l2 = _line(two.stdout)
+    assert l2["n_gpus"] == 2 and l2["reward_sha256"] == l1["reward_sha256"]
+    mg = l2["multi_gpu"]
+    assert mg["world_size"] == 2 and mg["launched_by"] == "bench.py" and mg["backend"] == "gloo"
+    assert [r["rank"] for r in mg["ranks"]] == [0, 1] and len({r["pid"] for r in mg["ranks"]}) == 2
+    assert mg["distinct_devices"] == 1                                    # the rehearsal shares the one GPU; a real node reports N
+    assert len(mg["per_rank_ms_per_step"]) == 2 and mg["exchange_us_per_step"] > 0
+
+
 def test_work_balanced_shards_of_the_planner_workload_on_two_ranks():
     """The shipped planner's pushes (uniform over the action box: most never reach the rope) sharded over two ranks by WORK -
     forwards left per candidate from adaptigraph_amd.rollout_work, identical on every rank, no exchange - on the one GPU of the
