@@ -34,8 +34,13 @@ The progress lines the reference prints on every call go to stdout only with `ve
 """
 from __future__ import annotations
 
+import logging
+
 import numpy as np
 import torch
+
+log = logging.getLogger("adaptigraph_amd.planner")
+_OWNER = "_chunk_owner"      # key of a result dictionary of a rank-dealt call: (index of the call in its series, owning rank)
 
 
 def farthest_points(points, num, init_idx=-1):
@@ -107,6 +112,37 @@ def _require_rank_local(fn, what):
                          "over the ranks with batch-global maxima.")
 
 
+def _broadcast_result(obj, src, pg, device):
+    """Nested dict / list / tuple result `obj` of rank `src` (global rank) -> the same structure on every rank of the group:
+    the structure, shapes and dtypes travel as one small pickled object, the tensors as one broadcast each."""
+    import torch.distributed as dist
+
+    def spec_of(o):
+        if isinstance(o, torch.Tensor):
+            return ("__tensor__", tuple(o.shape), o.dtype)
+        if isinstance(o, dict):
+            return {k: spec_of(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return type(o)(spec_of(v) for v in o)
+        return o
+
+    box = [spec_of(obj) if obj is not None else None]
+    dist.broadcast_object_list(box, src=src, group=pg)
+    it = iter(list(_tensors(obj))) if obj is not None else None
+
+    def build(sp):
+        if isinstance(sp, tuple) and len(sp) == 3 and sp[0] == "__tensor__":
+            t = next(it).contiguous() if it is not None else torch.empty(sp[1], dtype=sp[2], device=device)
+            dist.broadcast(t, src=src, group=pg)
+            return t
+        if isinstance(sp, dict):
+            return {k: build(v) for k, v in sp.items()}
+        if isinstance(sp, (list, tuple)):
+            return type(sp)(build(v) for v in sp)
+        return sp
+    return build(box[0])
+
+
 class Planner(object):
     _REQUIRED = ("action_dim", "model_rollout_fn", "evaluate_traj_fn", "n_sample", "n_look_ahead", "n_update_iter",
                  "reward_weight", "action_lower_lim", "action_upper_lim", "planner_type")
@@ -156,13 +192,43 @@ class Planner(object):
         # (6: measured on the shipped 40 x 500 configuration, tools/probe_loop_host.py - rope 161 / 151 / 159 ms per planner call
         # with 4 / 6 / 8 streams and eight hardware queues, granular 241 / 225 / 227, cloth 212 / 217 / 219)
         self.pipeline_chunks = int(config.get("pipeline_chunks", 6 if self._eng_rollout is not None else 0))
+        # Dealing defers a call's "Exceeds max dims" to merge_res, so it is tied to the caller having announced a chunk loop the
+        # way both reference call sites do - `planner.total_chunks = n_chunk` (plan.py:210, random_interact.py:188) - or having
+        # put 'pipeline_chunks' into the config itself.  A planner that is called once per MPC step and never merged
+        # (total_chunks 1) runs every call strictly: the exception is raised inside the call, as in the reference.
+        self._pipe_explicit = "pipeline_chunks" in config
         self._side = None            # (device, [streams])
         self._pipe_in = None         # (state_cur, act_seq, (versions, caller stream), entry event): inputs of the running series
         self._pipe_i = 0
         self._call_flags = None      # flag tensors of the rollouts of the call being enqueued
         self._pending = []           # (pinned flag copy, done event) of calls whose flags have not been looked at
+        self._series_i = 0           # calls since the last merge_res = index of the next call in the caller's chunk loop
+        self._series_err = None      # what a rank-dealt call raised: kept for merge_res, where all ranks agree on it
+        self._said = set()           # reasons already logged
         self.chunk_id = 0
         self.total_chunks = 1
+        why = self._pipeline_off_static()
+        if why and str(self.device) != "cpu":
+            self._say("planner: calls are not dealt to side streams (every call waits for its rollout) because " + why)
+
+    def _say(self, msg):
+        if msg not in self._said:
+            self._said.add(msg)
+            log.warning(msg)
+
+    def _pipeline_off_static(self):
+        """why the chunk loop cannot be dealt to side streams whatever the caller does later, or None"""
+        if self.planner_type != "MPPI":
+            return f"planner_type is {self.planner_type!r}"
+        if self._eng_rollout is None:
+            return ("model_rollout_fn is not functools.partial(adaptigraph_amd.dynamics, model=<DynamicsPredictor>, device=..., "
+                    "ppm_optimizer=...) with keyword arguments only (plan.py:190): a lambda, a positional argument or another "
+                    "callable is run as given")
+        if self.pipeline_chunks < 2:
+            return f"config['pipeline_chunks'] is {self.pipeline_chunks}"
+        if self.verbose:
+            return "config['verbose'] is set"
+        return None
 
     # ------------------------------------------------------------------------------------------ defaults of the config
     def sample_action_sequences_default(self, act_seq, iter_index=None):
@@ -217,8 +283,16 @@ class Planner(object):
         assert type(state_cur) == torch.Tensor and type(act_seq) == torch.Tensor
         assert act_seq.shape == (self.n_look_ahead, self.action_dim)
         if self.planner_type == "MPPI":
+            k = self._series_i
+            self._series_i += 1
+            world, rank, _ = self._loop_world()
+            if world > 1:
+                return self._rank_dealt(state_cur, act_seq, k, world, rank)
             if self._can_pipeline(state_cur):
-                return self._pipelined(state_cur, act_seq)
+                res = self._pipelined(state_cur, act_seq)
+                if self.total_chunks > 1 and k == self.total_chunks - 1:
+                    self.check_pending(block=True)           # the loop's last call: merge_res would wait here anyway
+                return res
             self.check_pending(block=True)                   # (a strict call: nothing of earlier calls stays unreported)
             return self.trajectory_optimization_mppi(state_cur, act_seq)
         if self.planner_type == "GD":
@@ -228,10 +302,66 @@ class Planner(object):
         raise ValueError("unknown planner type: %s" % self.planner_type)
 
     # ---------------------------------------------------------------- independent calls dealt to side streams (module docstring)
-    def _can_pipeline(self, state_cur):
-        # (not with a process group: an evaluation that issues collectives keeps its issue order on the caller's stream)
-        return (self.pipeline_chunks >= 2 and self._eng_rollout is not None and not self.verbose and state_cur.is_cuda
-                and self.group is None and not torch.cuda.is_current_stream_capturing())
+    def _loop_world(self):
+        """(world, rank, process group) the caller's chunk loop is dealt over: more than one rank only with config['group'], an
+        initialised torch.distributed and an announced loop (`planner.total_chunks = n_chunk`, plan.py:210)."""
+        if self.group is None or self.total_chunks <= 1 or self.verbose or not self.rollout_best:
+            return 1, 0, None
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1, 0, None
+        pg = None if self.group is True else self.group
+        return dist.get_world_size(pg), dist.get_rank(pg), pg
+
+    def _can_pipeline(self, state_cur, rank_dealt=False):
+        if self._pipeline_off_static() is not None:
+            return False
+        why = None
+        if not state_cur.is_cuda:
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        if self.group is not None and not rank_dealt:
+            # (an evaluation that issues collectives keeps its issue order on the caller's stream)
+            why = ("config['group'] is set but no chunk loop was announced: set planner.total_chunks = n_chunk (plan.py:210) and the "
+                   "calls are dealt to the ranks, chunk ci to rank ci % world")
+        elif self.total_chunks <= 1 and not self._pipe_explicit:
+            why = ("planner.total_chunks is 1: a lone call raises its own errors, as in the reference; announce the chunk loop with "
+                   "planner.total_chunks = n_chunk (plan.py:210, random_interact.py:188) or put 'pipeline_chunks' into the config")
+        if why:
+            self._say("planner: calls are not dealt to side streams because " + why)
+            return False
+        return True
+
+    # ------------------------------------------------- the caller's chunk loop dealt to the ranks of config['group'] (r06)
+    def _rank_dealt(self, state_cur, act_seq, k, world, rank):
+        """Call k of the announced loop (plan.py:241-247) on a multi-rank group: rank k % world evaluates it - on its side streams,
+        like a one-rank planner - and every other rank only draws the call's samples, so that all generators stay in step, and hands
+        back a placeholder.  merge_res all-gathers the winners.  Nothing is raised here (a rank that left the loop alone would
+        leave the others hanging in merge_res's collective): errors are kept for merge_res."""
+        if k == 0:
+            # the ranks evaluate different calls, so the callables must not issue collectives of their own
+            _require_rank_local(self.evaluate_traj, "evaluate_traj_fn")
+            _require_rank_local(self.model_rollout, "model_rollout_fn")
+        owner = k % world
+        if k >= self.total_chunks and self._series_err is None:
+            self._series_err = RuntimeError(f"call {k + 1} of a chunk loop announced with planner.total_chunks = {self.total_chunks}: "
+                                            "merge_res must close a series before the next one starts")
+        if owner == rank and self._series_err is None:
+            try:
+                if self._can_pipeline(state_cur, rank_dealt=True):
+                    res = self._pipelined(state_cur, act_seq, raise_early=False)
+                else:
+                    res = self.trajectory_optimization_mppi(state_cur, act_seq)
+                res[_OWNER] = (k, owner)
+                return res
+            except Exception as e:  # noqa: BLE001 - re-raised by merge_res on every rank
+                self._series_err = e
+        else:
+            for i in range(self.n_update_iter):              # same draws as the owner: shapes alone decide what a draw consumes
+                self.sample_action_sequences(act_seq, iter_index=i)
+        return {"act_seq": torch.full_like(act_seq, float("nan")), "model_outputs": None, "eval_outputs": None,
+                "best_model_output": None, "best_eval_output": None, _OWNER: (k, owner)}
 
     def _limits_of_rollout(self):
         from .forward_dynamics import _repeat_bound
@@ -278,10 +408,11 @@ class Planner(object):
             self._pending = []
             raise err
 
-    def _pipelined(self, state_cur, act_seq):
+    def _pipelined(self, state_cur, act_seq, raise_early=True):
         dev = state_cur.device
         cur = torch.cuda.current_stream(dev)
-        self.check_pending(block=False)
+        if raise_early:
+            self.check_pending(block=False)
         # Are these the inputs of the previous call, untouched?  (same tensor objects, same version counters, same caller
         # stream.)  Then they were ready where that series started and this call need not queue up behind the previous one.
         tag = (state_cur._version, act_seq._version, cur.cuda_stream)
@@ -335,13 +466,23 @@ class Planner(object):
             reward_seqs = eval_out["reward_seqs"]
             act_seq = self.optimize_action(act_seqs, reward_seqs)
             top = torch.argmax(reward_seqs)
-            if i == 0 or reward_seqs[top] > best_reward:
-                # (index_select, not act_seqs[top]: indexing with a 0-d GPU tensor makes torch read it back - a wait for the
-                # whole rollout and evaluation that the reference's own loop pays, planner.py:256-257; same values)
-                sel = top.reshape(1)
-                best_act_seq, best_reward = torch.index_select(act_seqs, 0, sel)[0], torch.index_select(reward_seqs, 0, sel)[0]
-                if self.reuse_best_rollout:
-                    best_rows = self._pick(model_out, top, act_seqs.shape[0])
+            # planner.py:254-260 `if i == 0 or reward_seqs[top] > best_reward: keep this round's best` without turning a 0-d GPU
+            # tensor into a Python bool (a wait for the whole rollout and evaluation, once per update iteration - five per call in
+            # random_interact.py's configuration): index_select instead of act_seqs[top], and the comparison stays on the device
+            # as the condition of torch.where.  Same values, same winner.
+            sel = top.reshape(1)
+            round_act, round_reward = torch.index_select(act_seqs, 0, sel)[0], torch.index_select(reward_seqs, 0, sel)[0]
+            round_rows = self._pick(model_out, top, act_seqs.shape[0]) if self.reuse_best_rollout else None
+            if i == 0:
+                best_act_seq, best_reward, best_rows = round_act, round_reward, round_rows
+            else:
+                better = round_reward > best_reward                                  # 0-d bool, stays where the rewards are
+                best_act_seq = torch.where(better, round_act, best_act_seq)
+                if round_rows is not None:
+                    best_rows = {key: (torch.where(better.to(v.device), v, best_rows[key])
+                                       if isinstance(v, torch.Tensor) and isinstance(best_rows[key], torch.Tensor)
+                                       and v.shape == best_rows[key].shape else v) for key, v in round_rows.items()}
+                best_reward = torch.where(better, round_reward, best_reward)
             if self.verbose:
                 model_outputs.append(model_out)
                 eval_outputs.append(eval_out)
@@ -365,12 +506,66 @@ class Planner(object):
     def merge_res(self, res_list):
         """planner.py:311-323: the chunk whose winner scores best in its own batch-of-one re-evaluation."""
         assert not self.verbose and self.rollout_best
+        self._series_i = 0
+        self._pipe_in = None                                  # the next series records its own entry event
+        if any(isinstance(res, dict) and _OWNER in res for res in res_list):
+            return self._merge_rank_dealt(res_list)
         self.check_pending(block=True)                        # flags of the pipelined calls: here the reference's loop syncs too
         # (one read-back for all chunks; .mean() of the (1,) reward and the Python float are the reference's, planner.py:312-314)
         scores = torch.stack([res["best_eval_output"]["reward_seqs"].mean() for res in res_list]).tolist()
         win = res_list[int(np.argmax(scores))]
         return {"act_seq": win["act_seq"], "model_outputs": None, "eval_outputs": None,
                 "best_model_output": win["best_model_output"], "best_eval_output": win["best_eval_output"]}
+
+    def _merge_rank_dealt(self, res_list):
+        """merge_res of a loop whose calls were dealt to the ranks (_rank_dealt): one all-gather of (error code, winner's score,
+        winner's action sequence) per call - n_chunk x (2 + n_look_ahead x action_dim) numbers -, the reference's argmax over the
+        scores on every rank, and the winning call's best_model_output / best_eval_output broadcast from its owner.  An error
+        any rank met during the series ("Exceeds max dims", ...) is raised here on EVERY rank, after the exchange."""
+        import torch.distributed as dist
+        world, rank, pg = self._loop_world()
+        err, self._series_err = self._series_err, None
+        n, H, A = len(res_list), self.n_look_ahead, self.action_dim
+        try:
+            self.check_pending(block=True)
+        except Exception as e:  # noqa: BLE001
+            err = err or e
+        if world <= 1:                                        # (the group went away between the calls and the merge)
+            raise err or RuntimeError("merge_res: results of a rank-dealt chunk loop, but no multi-rank group")
+        like = res_list[0]["act_seq"]
+        per = (n + world - 1) // world
+        table = torch.zeros((per, 2 + H * A), dtype=like.dtype, device=like.device)
+        table[:, 1] = float("-inf")
+        if err is None:
+            try:
+                for k, res in enumerate(res_list):
+                    assert res.get(_OWNER) == (k, k % world), "merge_res needs the results of ALL calls of the series, in call order"
+                    if k % world == rank:
+                        table[k // world, 1] = res["best_eval_output"]["reward_seqs"].mean().to(like.dtype)
+                        table[k // world, 2:] = res["act_seq"].reshape(-1)
+            except Exception as e:  # noqa: BLE001
+                err = e
+        table[:, 0] = 0.0 if err is None else (1.0 if str(err) == "Exceeds max dims" else 2.0)
+        gathered = torch.empty((world * per, 2 + H * A), dtype=like.dtype, device=like.device)
+        dist.all_gather_into_tensor(gathered, table, group=pg)
+        host = gathered.cpu()                                 # the one wait of the loop, where the reference's first .item() is
+        codes = host[:, 0]
+        if float(codes.max()) > 0:
+            if err is not None:
+                raise err
+            if float(codes.max()) == 1.0 and not bool((codes == 2.0).any()):
+                raise Exception("Exceeds max dims")           # utils.py:63-65, met by another rank
+            bad = sorted({int(i) // per for i in torch.nonzero(codes).reshape(-1)})
+            raise RuntimeError(f"planner: rank(s) {bad} failed during the chunk loop (their own exception says why)")
+        row = lambda k: (k % world) * per + k // world
+        scores = [float(host[row(k), 1]) for k in range(n)]   # planner.py:312-314: Python floats, first maximum wins
+        win = int(np.argmax(scores))
+        owner = win % world
+        src = owner if pg is None else dist.get_global_rank(pg, owner)
+        act = gathered[row(win), 2:].reshape(H, A).clone()
+        mine = (res_list[win]["best_model_output"], res_list[win]["best_eval_output"]) if rank == owner else None
+        best_model, best_eval = _broadcast_result(mine, src, pg, like.device)
+        return {"act_seq": act, "model_outputs": None, "eval_outputs": None, "best_model_output": best_model, "best_eval_output": best_eval}
 
     # ---------------------------------------------------------------------------------- all chunks in two rollout calls
     @staticmethod
@@ -395,11 +590,15 @@ class Planner(object):
         assert type(state_cur) == torch.Tensor and type(act_seq) == torch.Tensor
         assert act_seq.shape == (self.n_look_ahead, self.action_dim)
         if self.planner_type != "MPPI" or self.n_update_iter != 1 or not self.rollout_best or self.verbose or n_chunk < 1:
-            res_all = []
-            for ci in range(n_chunk):
-                self.chunk_id = ci
-                res_all.append(self.trajectory_optimization(state_cur, act_seq))
-            return self.merge_res(res_all)
+            res_all, announced = [], self.total_chunks
+            self.total_chunks = n_chunk                       # the loop as plan.py:210, 241-247 announces and runs it
+            try:
+                for ci in range(n_chunk):
+                    self.chunk_id = ci
+                    res_all.append(self.trajectory_optimization(state_cur, act_seq))
+                return self.merge_res(res_all)
+            finally:
+                self.total_chunks = announced
         import torch.distributed as dist
         from .sharding import shard_bounds, all_gather_costs
         sharded = self.group is not None and dist.is_available() and dist.is_initialized()

@@ -788,6 +788,7 @@ def test_planner_class_chunk_loop_equals_chunked_entry_on_the_engine(ag, O, dev)
     act_seq = torch.rand((H, 4), device=dev) * (hi - lo) + lo
     torch.manual_seed(4)
     res_all = []
+    planner.total_chunks = n_chunk                                      # plan.py:210
     for ci in range(n_chunk):                                           # plan.py:241-247
         planner.chunk_id = ci
         res = planner.trajectory_optimization(s0, act_seq)

@@ -130,3 +130,27 @@ def test_work_balanced_shards_of_the_planner_workload_on_two_ranks():
     assert [r["executed"] for r in wb["per_rank"]] == f, (wb["per_rank"], f)
     print(f"2 ranks, {l2['never_touch_fraction']:.0%} never touch: work-balanced forwards {f} (candidates {n}), count-balanced "
           f"{cb['forwards_per_rank']}")
+
+
+def test_the_unchanged_planner_loop_dealt_to_two_ranks_equals_one_rank():
+    """The reference's own chunk loop (plan.py:210, 241-247) on the shipped rope configuration, planner_config['group'] set, two
+    ranks on the one GPU of the box (gloo): the merged result - winning action, its rollout, its reward - equals the one-rank loop's
+    bit for bit, every rank holds it, the generators end in the same state, each rank rolled out every second call only.  Also
+    with random_interact.py's n_update_iter 5 (the in-call best-so-far selection stays on the device)."""
+    tool = os.path.join(ROOT, "tools", "two_rank_planner_loop.py")
+    for upd, chunks in ((1, 12), (5, 3)):
+        env = dict(_clean_env(), AG_LOOP_CHUNKS=str(chunks), AG_LOOP_REPS="1", AG_LOOP_UPDATE_ITER=str(upd))
+        one = subprocess.run([sys.executable, tool], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+        l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), tool],
+                             env=dict(env, AG_BENCH_SHARE_GPU="1"), cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+        l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+        assert l1["world"] == 1 and l2["world"] == 2 and l2["n_update_iter"] == upd
+        assert l2["same_result_on_every_rank"] and l2["generators_in_step"]
+        assert l2["result_sha256"] == l1["result_sha256"] and l2["generator_sha256"] == l1["generator_sha256"], (l1, l2)
+        assert l2["calls_owned_per_rank"] == [(chunks + 1) // 2, chunks // 2]
+        print(f"n_update_iter {upd}, {chunks} chunks: planner call {l1['ms_per_planner_call']:.1f} ms on one rank, "
+              f"{l2['ms_per_planner_call']:.1f} ms on two ranks sharing the GPU")

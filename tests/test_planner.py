@@ -199,3 +199,115 @@ def test_chunks_dealt_to_two_gloo_ranks_give_the_reference_result():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True, [3 * 16, 5]), (1, True, [2 * 16, 5])]
+
+
+# ------------------------------------------- the reference's UNCHANGED chunk loop dealt to the ranks of config['group'] (r06)
+def _reference_loop(pl, state_cur, act0, n_chunk):
+    """plan.py:210, 241-247 as written there"""
+    pl.total_chunks = n_chunk
+    res_all = []
+    for ci in range(n_chunk):
+        pl.chunk_id = ci
+        res = pl.trajectory_optimization(state_cur, act0)
+        for k, v in res.items():
+            res[k] = v.detach().clone() if isinstance(v, torch.Tensor) else v
+        res_all.append(res)
+    return pl.merge_res(res_all), res_all
+
+
+def _loop_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_golden("planner")
+    act0, state_cur = torch.from_numpy(g["act0"]), torch.from_numpy(g["state_cur"])
+    out = {"rank": rank}
+    # (1) the golden case of the reference's own Planner: 5 chunks, n_update_iter 1, seed 36
+    calls = []
+    pl = _planner(n_update_iter=1, group=True, model_rollout_fn=lambda s, a: (calls.append(a.shape[0]), toy_rollout(s, a))[1])
+    torch.manual_seed(36)
+    merged, res_all = _reference_loop(pl, state_cur, act0.clone(), 5)
+    out["golden"] = bool(np.array_equal(merged["act_seq"].numpy(), g["d_act_seq"]) and
+                         np.array_equal(merged["best_eval_output"]["reward_seqs"].numpy(), g["d_best_reward"]))
+    out["calls"] = list(calls)
+    out["owners"] = [r["_chunk_owner"] for r in res_all]
+    out["placeholders_are_nan"] = all(bool(torch.isnan(r["act_seq"]).all()) == (r["_chunk_owner"][1] != rank) for r in res_all)
+    # (2) n_update_iter 3 (the in-call where() selection), 7 chunks, against the one-rank loop run in this very process
+    one = _planner(n_update_iter=3)
+    torch.manual_seed(77)
+    want, _ = _reference_loop(one, state_cur, act0.clone(), 7)
+    end_state = torch.get_rng_state()
+    pl3 = _planner(n_update_iter=3, group=True)
+    torch.manual_seed(77)
+    got, _ = _reference_loop(pl3, state_cur, act0.clone(), 7)
+    out["equal_one_rank"] = bool(torch.equal(got["act_seq"], want["act_seq"]) and
+                                 torch.equal(got["best_model_output"]["state_seqs"], want["best_model_output"]["state_seqs"]) and
+                                 torch.equal(got["best_model_output"]["action_seqs"], want["best_model_output"]["action_seqs"]) and
+                                 torch.equal(got["best_eval_output"]["reward_seqs"], want["best_eval_output"]["reward_seqs"]) and
+                                 sorted(got) == sorted(want))
+    out["generator_in_step"] = bool(torch.equal(torch.get_rng_state(), end_state))
+    # (3) a second series on the same planner works (the series counter was closed by merge_res)
+    torch.manual_seed(77)
+    again, _ = _reference_loop(pl3, state_cur, act0.clone(), 7)
+    out["second_series"] = bool(torch.equal(again["act_seq"], want["act_seq"]))
+    # (4) "Exceeds max dims" on ONE rank's call (call 2 of 6 -> rank 2 % world) is raised by merge_res on EVERY rank
+    n_calls = [0]
+
+    def overflowing(s, a):
+        n_calls[0] += 1
+        if a.shape[0] > 1 and float(a[0, 0, 0]) == float(marker[0]):
+            raise Exception("Exceeds max dims")
+        return toy_rollout(s, a)
+    bad = _planner(n_update_iter=1, group=True, model_rollout_fn=overflowing)
+    torch.manual_seed(5)
+    probe = [_planner(n_update_iter=1).sample_action_sequences(act0.clone(), iter_index=0) for _ in range(3)]
+    marker = [float(probe[2][0, 0, 0])]                           # first number of the samples of call 2
+    torch.manual_seed(5)
+    try:
+        _reference_loop(bad, state_cur, act0.clone(), 6)
+        out["error_everywhere"] = False
+    except Exception as e:  # noqa: BLE001
+        out["error_everywhere"] = str(e) == "Exceeds max dims"
+    # ... and the planner is usable afterwards
+    torch.manual_seed(36)
+    merged2, _ = _reference_loop(pl, state_cur, act0.clone(), 5)
+    out["usable_after_error"] = bool(np.array_equal(merged2["act_seq"].numpy(), g["d_act_seq"]))
+    # (5) callables that issue their own collectives are refused on every rank (at the merge, like every error of the loop)
+    from functools import partial
+
+    def cost_with_collective(state_seqs, act_seqs, state_cur=None, group=None, **kw):
+        return toy_cost(state_seqs, act_seqs, state_cur=state_cur)
+    refused = _planner(n_update_iter=1, group=True, evaluate_traj_fn=partial(cost_with_collective, group=True))
+    try:
+        _reference_loop(refused, state_cur, act0.clone(), 4)
+        out["refused"] = False
+    except ValueError as e:
+        out["refused"] = "rank-local" in str(e)
+    q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_the_references_chunk_loop_is_dealt_to_the_ranks_and_merges_to_the_one_rank_result(world):
+    """planner_config['group'] + `planner.total_chunks = n_chunk` (plan.py:210): call ci of the loop of plan.py:241-247 runs on
+    rank ci % world, the others draw its samples and get a placeholder; merge_res all-gathers the winners and broadcasts the best
+    one's outputs.  Bit-equal to the one-rank loop (and to the reference Planner's own recorded result), generators in step,
+    errors raised on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loop_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda o: o["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, o in enumerate(res):
+        mine = [k for k in range(5) if k % world == r]
+        assert o["calls"] == [16, 1] * len(mine), o              # only its own chunks were rolled out (+ each one's winner, planner.py:270)
+        assert o["owners"] == [(k, k % world) for k in range(5)]
+        for key in ("golden", "placeholders_are_nan", "equal_one_rank", "generator_in_step", "second_series", "error_everywhere",
+                    "usable_after_error", "refused"):
+            assert o[key] is True, (r, key, o)

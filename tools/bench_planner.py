@@ -68,6 +68,7 @@ def make_planner(mat, n_sample, rng):
 
 def loop_call(planner, s0, act_seq, n_chunk):
     res_all = []
+    planner.total_chunks = n_chunk                                       # plan.py:210
     for ci in range(n_chunk):                                            # plan.py:241-247
         planner.chunk_id = ci
         res = planner.trajectory_optimization(s0, act_seq)

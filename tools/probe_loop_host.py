@@ -32,6 +32,7 @@ def main():
                     torch.manual_seed(1)
                     t0 = time.perf_counter()
                     res_all = []
+                    planner.total_chunks = 40
                     for ci in range(40):
                         planner.chunk_id = ci
                         res_all.append(planner.trajectory_optimization(s0, act_seq))
