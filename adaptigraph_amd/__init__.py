@@ -15,7 +15,7 @@ import os as _os
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .context import Engine, default_engine
-from .forward_dynamics import dynamics, dynamics_masked, rollout_work
+from .forward_dynamics import dynamics, dynamics_masked, dynamics_mixed, rollout_work
 from .graph import (EdgeList, construct_edges_from_states_batch, construct_edges_from_states, construct_edges_index,
                     construct_edges_with_backoff, pad_torch, truncate_graph)
 from .model import DynamicsPredictor
@@ -26,7 +26,7 @@ from .physics_param_optimizer import dynamics_error, dynamics_error_sweep
 from .mppi import angle_normalize, clip_actions, sample_action_seq, optimize_action_mppi, mpc_iteration
 from .planner import Planner
 
-__all__ = ["Engine", "default_engine", "dynamics", "dynamics_masked", "rollout_work", "EdgeList", "construct_edges_from_states_batch", "construct_edges_from_states",
+__all__ = ["Engine", "default_engine", "dynamics", "dynamics_masked", "dynamics_mixed", "rollout_work", "EdgeList", "construct_edges_from_states_batch", "construct_edges_from_states",
            "construct_edges_index", "construct_edges_with_backoff", "pad_torch", "truncate_graph", "DynamicsPredictor", "decode_action", "chamfer",
            "mean_chamfer", "box_loss", "rope_penalty", "cloth_penalty", "granular_penalty", "running_cost", "dynamics_error", "dynamics_error_sweep", "angle_normalize",
            "clip_actions", "sample_action_seq", "optimize_action_mppi", "mpc_iteration", "Planner"]

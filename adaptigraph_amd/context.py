@@ -169,6 +169,20 @@ class Engine:
         return self._ctx
 
 
+_SIDE_STREAMS = {}
+
+
+def side_streams(device, n):
+    """The same n side streams for every dealt evaluation on a device (dynamics_error_sweep, dynamics_mixed): the engine keeps one
+    call slot per caller stream, so fresh streams per call would only make it recycle slots."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    have = _SIDE_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device))
+    return have[:n]
+
+
 _default_engines = {}
 
 

@@ -240,3 +240,51 @@ def dynamics_masked(state_init, state_mask, action, model, device, ppm_optimizer
     out = _run(model, dev, task, ppm_optimizer, physics_param, B, 1, N_o, 1, state0, mask_u8, xz, delta, repeat,
                sync=_sync, overflow_flag=_overflow_flag)
     return {"state_seqs": out[:, 0], "action_seqs": decoded[:, 0].to(action.device)}
+
+
+@torch.no_grad()
+def dynamics_mixed(batches, device, one_stream_each=None):
+    """One evaluation of a MIXED batch of variable-size graphs (BASELINE configs[4]: rope + granular + cloth candidates, every one
+    with its own particle count, graph rebuilt every step): `batches` is a list of per-material argument tuples
+        (state_init (B_m,max_nobj_m,3), state_mask (B_m,max_nobj_m), action (B_m,4), model_m, ppm_optimizer_m[, physics_param_m])
+    i.e. what one would hand to dynamics_masked (forward_dynamics.py:209-399) material by material, each material with its own model
+    (= its own engine context and weights).  -> [dynamics_masked's result dictionary per batch], bit-equal to the sequential calls.
+
+    The materials do not depend on each other, so batch m is enqueued on side stream m without waiting for anything
+    (dynamics_masked(_sync=False) on that context's per-stream call slot) and the small graphs' latency-bound launch chains run
+    under the large graphs' kernels; the caller's stream waits (on the GPU) for all of them, and ONE read-back brings every
+    batch's flags: Exception("Exceeds max dims") (utils.py:63-65) if any graph of any batch outgrew its max_nR.  Pass CPU-resident
+    actions / physics parameters to keep the call free of other read-backs.
+    one_stream_each: keep every engine on its one side stream (None: only when more than two batches share the chip)."""
+    from .context import side_streams
+    dev = _require_gpu(device)
+    n = len(batches)
+    if n == 0:
+        return []
+    flags = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    cur = torch.cuda.current_stream(dev)
+    entry = torch.cuda.Event()
+    entry.record(cur)
+    side = side_streams(dev, n)
+    pin = (n > 2) if one_stream_each is None else bool(one_stream_each)
+    out = []
+    for m, (batch, st) in enumerate(zip(batches, side)):
+        state_init, state_mask, action, model, ppm = batch[:5]
+        phys = batch[5] if len(batch) > 5 else None
+        st.wait_event(entry)
+        with torch.cuda.stream(st):
+            if pin and isinstance(model, DynamicsPredictor):
+                with model.engine(dev).options(streams=1):
+                    res = dynamics_masked(state_init, state_mask, action, model, dev, ppm, physics_param=phys, _sync=False, _overflow_flag=flags[m])
+            else:
+                res = dynamics_masked(state_init, state_mask, action, model, dev, ppm, physics_param=phys, _sync=False, _overflow_flag=flags[m])
+        done = torch.cuda.Event()
+        done.record(st)
+        cur.wait_event(done)
+        res["state_seqs"].record_stream(cur)
+        out.append(res)
+    seen = flags.tolist()                                                              # the one wait of the call
+    for (batch, (seen_nR, _)) in zip(batches, seen):
+        if seen_nR > int(batch[4].task_config["max_nR"]):
+            raise Exception("Exceeds max dims")                                        # utils.py:63-65
+    return out

@@ -10,6 +10,7 @@ import copy
 import numpy as np
 import torch
 
+from .context import side_streams as _sweep_streams
 from .forward_dynamics import dynamics_masked
 from .losses import mean_chamfer
 
@@ -51,19 +52,6 @@ def dynamics_error(physics_param, ppm_optimizer, state_init_list, state_real_lis
     before, before_valid, after, after_valid, pushes = _problem(ppm_optimizer, state_init_list, state_real_list, actions)
     rolled = dynamics_masked(before, before_valid, pushes, ppm_optimizer.model, device, ppm_optimizer, physics_param=physics_param)
     return mean_chamfer(rolled["state_seqs"].detach(), after, before_valid, after_valid).mean()
-
-
-_SWEEP_STREAMS = {}
-
-
-def _sweep_streams(device, n):
-    """the same n side streams for every sweep on a device (the engine keeps one call slot per caller stream: fresh streams per
-    sweep would only make it recycle slots)"""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    have = _SWEEP_STREAMS.setdefault(key, [])
-    while len(have) < n:
-        have.append(torch.cuda.Stream(device))
-    return have[:n]
 
 
 @torch.no_grad()

@@ -201,6 +201,8 @@ class Planner(object):
         self._pipe_in = None         # (state_cur, act_seq, (versions, caller stream), entry event): inputs of the running series
         self._pipe_i = 0
         self._call_flags = None      # flag tensors of the rollouts of the call being enqueued
+        self._call_one_stream = True # the call being enqueued keeps the engine on its one stream (dealt calls)
+        self._bound_ok = None        # (_repeats_within_bound's verdict,) once decided
         self._pending = []           # (pinned flag copy, done event) of calls whose flags have not been looked at
         self._series_i = 0           # calls since the last merge_res = index of the next call in the caller's chunk loop
         self._series_err = None      # what a rank-dealt call raised: kept for merge_res, where all ranks agree on it
@@ -294,6 +296,8 @@ class Planner(object):
                     self.check_pending(block=True)           # the loop's last call: merge_res would wait here anyway
                 return res
             self.check_pending(block=True)                   # (a strict call: nothing of earlier calls stays unreported)
+            if self._can_wait_once(state_cur):
+                return self._one_wait_call(state_cur, act_seq)
             return self.trajectory_optimization_mppi(state_cur, act_seq)
         if self.planner_type == "GD":
             return self.trajectory_optimization_gd(state_cur, act_seq)
@@ -325,6 +329,8 @@ class Planner(object):
             # (an evaluation that issues collectives keeps its issue order on the caller's stream)
             why = ("config['group'] is set but no chunk loop was announced: set planner.total_chunks = n_chunk (plan.py:210) and the "
                    "calls are dealt to the ranks, chunk ci to rank ci % world")
+        elif self._repeats_within_bound() is not None:
+            why = self._repeats_within_bound() + ": every call waits for its rollout so that it can fall back to the host decode"
         elif self.total_chunks <= 1 and not self._pipe_explicit:
             why = ("planner.total_chunks is 1: a lone call raises its own errors, as in the reference; announce the chunk loop with "
                    "planner.total_chunks = n_chunk (plan.py:210, random_interact.py:188) or put 'pipeline_chunks' into the config")
@@ -351,6 +357,8 @@ class Planner(object):
             try:
                 if self._can_pipeline(state_cur, rank_dealt=True):
                     res = self._pipelined(state_cur, act_seq, raise_early=False)
+                elif self._can_wait_once(state_cur):
+                    res = self._one_wait_call(state_cur, act_seq)
                 else:
                     res = self.trajectory_optimization_mppi(state_cur, act_seq)
                 res[_OWNER] = (k, owner)
@@ -377,10 +385,55 @@ class Planner(object):
         # a dealt call stays on its one stream (option streams = 1 for the duration of the enqueue): six of them already run side
         # by side, and a fork inside each doubles the launches and lets in-library streams share hardware queues with the side
         # streams (rope planner call 168 +- 10 ms with the engine's by-size fork, 147 without, run after run)
+        if not self._call_one_stream:                        # a lone call on the caller's stream: the engine forks by size as always
+            return self._eng_rollout(state_cur, act_seqs, _sync=False, _overflow_flag=flags)
         kw = self._eng_rollout.keywords
         eng = kw["model"].engine(torch.device(kw["device"]))
         with eng.options(streams=1):
             return self._eng_rollout(state_cur, act_seqs, _sync=False, _overflow_flag=flags)
+
+    def _repeats_within_bound(self):
+        """None if no sampled action can carry an action_repeat beyond what the engine's device-planned rollout serves
+        (task_config['action_upper_lim'][3]), else why that cannot be ruled out.  Only then may a rollout be enqueued without
+        waiting for it: a call that waits (`dynamics(_sync=True)`) falls back to the host decode for such an action, as the
+        reference accepts any push length (forward_dynamics.py:156), and a call that does not wait could only raise.  Decided
+        once, from the limits the sampler and the MPPI update clamp to (read back once: this is not the hot path)."""
+        if self._bound_ok is not None:
+            return self._bound_ok[0]
+        import functools
+        from .forward_dynamics import _repeat_bound
+        from . import mppi as _mppi
+        why = None
+        bound = _repeat_bound(self._eng_rollout.keywords["ppm_optimizer"].task_config)
+        uppers = []
+        for what, fn, mine, theirs in (("sampling_action_seq_fn", self.sample_action_sequences, self.sample_action_sequences_default, _mppi.sample_action_seq),
+                                       ("optimize_action_mppi_fn", self.optimize_action_mppi, self.optimize_action_mppi_default, _mppi.optimize_action_mppi)):
+            if getattr(fn, "__func__", None) is getattr(mine, "__func__", object()) and getattr(fn, "__self__", None) is self:
+                if what == "optimize_action_mppi_fn" and self.clip_action_sequences != self.clip_actions_default and not (
+                        isinstance(self.clip_action_sequences, functools.partial) and self.clip_action_sequences.func is _mppi.clip_actions):
+                    why = "clip_action_seq_fn is not the planner's own clamp or adaptigraph_amd.clip_actions"
+                uppers.append(self.action_upper_lim)
+            elif isinstance(fn, functools.partial) and fn.func is theirs and fn.keywords.get("action_upper_lim") is not None:
+                uppers.append(fn.keywords["action_upper_lim"])
+            else:
+                why = f"{what} is neither the planner's default nor functools.partial(adaptigraph_amd.{theirs.__name__}, action_upper_lim=...)"
+        if isinstance(self.clip_action_sequences, functools.partial) and self.clip_action_sequences.func is _mppi.clip_actions \
+                and self.clip_action_sequences.keywords.get("action_upper_lim") is not None:
+            uppers.append(self.clip_action_sequences.keywords["action_upper_lim"])
+        if bound is None:
+            why = "task_config has no 'action_upper_lim' (planning/*.yaml:28-29) to bound action_repeat with"
+        elif why is None:
+            try:
+                top = max(float(torch.as_tensor(u).reshape(-1)[3]) for u in uppers) if self.action_dim == 4 else None
+            except (IndexError, TypeError, ValueError):
+                top = None
+            if top is None or not int(top) <= bound:
+                why = (f"the planner's limits allow a push length of {top} but task_config['action_upper_lim'][3] bounds action_repeat "
+                       f"by {bound}")
+        if why is not None:
+            why = "an action_repeat beyond the task config's bound cannot be ruled out (" + why + ")"
+        self._bound_ok = (why,)
+        return why
 
     def check_pending(self, block=True):
         """Look at the flags of the pipelined calls that have finished (block: wait for all of them): raises what their
@@ -407,6 +460,29 @@ class Planner(object):
         if err is not None:
             self._pending = []
             raise err
+
+    def _can_wait_once(self, state_cur):
+        """A call that is not dealt (a lone call, or config['pipeline_chunks'] = 1) still need not wait after EVERY rollout of its
+        n_update_iter rounds: with the engine's own dynamics() and repeats that cannot leave the bound it enqueues all rounds on the
+        caller's stream and reads all flags once, before it returns - "Exceeds max dims" is raised by the call itself, as in the
+        reference (utils.py:63-65), only after the later rounds were enqueued.  config['pipeline_chunks'] = 0: off."""
+        return (self._eng_rollout is not None and self.pipeline_chunks != 0 and not self.verbose and state_cur.is_cuda
+                and not torch.cuda.is_current_stream_capturing() and self._repeats_within_bound() is None)
+
+    def _one_wait_call(self, state_cur, act_seq):
+        self._call_flags, self._call_one_stream = [], False
+        try:
+            res = self.trajectory_optimization_mppi(state_cur, act_seq)
+            flags = self._call_flags
+        finally:
+            self._call_flags, self._call_one_stream = None, True
+        if flags:
+            max_nR, bound = self._limits_of_rollout()
+            for seen_nR, seen_rep in torch.stack(flags).tolist():          # the one wait of the call
+                if seen_nR > max_nR:
+                    raise Exception("Exceeds max dims")                    # utils.py:63-65
+                assert bound is None or seen_rep <= bound, "an action_repeat beyond the bound (_repeats_within_bound said it cannot happen)"
+        return res
 
     def _pipelined(self, state_cur, act_seq, raise_early=True):
         dev = state_cur.device

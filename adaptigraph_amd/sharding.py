@@ -42,6 +42,49 @@ def shard_bounds_weighted(weights, world: int, rank: int):
     return cuts[rank], cuts[rank + 1]
 
 
+def mixed_shard_bounds(weights_per_batch, world: int):
+    """Shards of a MIXED batch (BASELINE configs[4]: several materials, each a ragged batch of its own) cut by work over ALL
+    materials at once: the candidates are taken in batch order (all of batch 0, then batch 1, ...), the weights concatenated -
+    a candidate's work estimate is N_b * (topk + M) of ITS material, so a cloth candidate weighs ~6x a rope one - and the
+    concatenated sequence is cut into `world` contiguous pieces by shard_bounds_weighted.  Returns [rank][batch] -> (lo, hi):
+    the rows of every batch a rank evaluates (empty ranges where a rank's piece does not reach into a batch).  Every rank
+    computes the same table from the same numbers."""
+    import numpy as np
+    sizes = [len(w) for w in weights_per_batch]
+    flat = np.concatenate([np.asarray(w, dtype=np.float64) for w in weights_per_batch]) if sizes else np.zeros(0)
+    starts = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    table = []
+    for r in range(world):
+        lo, hi = shard_bounds_weighted(flat, world, r)
+        table.append([(int(min(max(lo, a), b) - a), int(min(max(hi, a), b) - a)) for a, b in zip(starts[:-1], starts[1:])])
+    return table
+
+
+def sharded_mixed_values(weights_per_batch, evaluate_rows, group=None):
+    """Per-candidate values of a mixed batch with every rank evaluating its mixed_shard_bounds piece: evaluate_rows(m, lo, hi) ->
+    (hi - lo,) tensor for rows [lo, hi) of batch m (called only for non-empty ranges).  -> [full (B_m,) tensor per batch] on
+    every rank: one all-gather of the rank's concatenated values, variable-length pieces."""
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    table = mixed_shard_bounds(weights_per_batch, world)
+    sizes = [len(w) for w in weights_per_batch]
+    pieces = [evaluate_rows(m, lo, hi) for m, (lo, hi) in enumerate(table[rank]) if hi > lo]
+    if pieces:
+        local = torch.cat([p.reshape(-1) for p in pieces])
+    else:                                                   # a rank without rows still takes part in the all-gather
+        local = torch.zeros(0, device="cuda" if distributed and dist.get_backend(group) == "nccl" else "cpu")
+    starts = [0]
+    for n in sizes:
+        starts.append(starts[-1] + n)
+    bounds = []
+    for r in range(world):
+        rows = [(starts[m] + lo, starts[m] + hi) for m, (lo, hi) in enumerate(table[r]) if hi > lo]
+        bounds.append((rows[0][0], rows[-1][1]) if rows else (bounds[-1][1] if bounds else 0,) * 2)
+    full = all_gather_costs(local.contiguous(), starts[-1], group, bounds=bounds) if world > 1 else local
+    return [full[starts[m]:starts[m + 1]] for m in range(len(sizes))]
+
+
 def all_gather_costs(cost_local: torch.Tensor, n_candidates: int, group=None, bounds=None) -> torch.Tensor:
     """cost_local: (hi-lo,) costs of this rank's shard -> (n_candidates,) costs of the whole batch on every rank.
     bounds: optional list of (lo, hi) per rank for work-balanced shards (default: shard_bounds)."""
@@ -99,7 +142,28 @@ def work_balanced_bounds(work, world: int):
     can differ several-fold in work.  Every rank computes the same cuts from the same numbers."""
     import numpy as np
     w = np.asarray(work, dtype=np.float64) + WORK_FLOOR
-    return [shard_bounds_weighted(w, world, r) for r in range(world)]
+    cuts = [shard_bounds_weighted(w, world, r)[0] for r in range(world)] + [len(w)]
+    if len(w) >= world:                                    # no rank is left without a candidate (a rollout of zero rows)
+        for r in range(1, world):
+            cuts[r] = max(cuts[r], cuts[r - 1] + 1)
+        for r in range(world - 1, 0, -1):
+            cuts[r] = min(cuts[r], cuts[r + 1] - 1)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def bounds_of_rank0(bounds, group=None):
+    """[(lo, hi)] per rank as RANK 0 computed them, on every rank (one broadcast of world + 1 integers).  Work-balanced bounds come
+    out of a per-rank work estimate - forward_dynamics.rollout_work goes through the rank's own engine context, whose kept base
+    rollout and census verdict decide whether the estimate counts prefix-shared forwards - so two ranks can arrive at different
+    cuts from the same batch; bounds that size an all-gather must be ONE rank's (different layouts would permute the rewards
+    silently, different sizes would hang).  Any contiguous cut gives the same rewards bit for bit; only the balance is rank 0's."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bounds
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([b[0] for b in bounds] + [bounds[-1][1]], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+    cuts = t.tolist()
+    return [(int(cuts[r]), int(cuts[r + 1])) for r in range(len(bounds))]
 
 
 def sharded_candidate_rewards(actions: torch.Tensor, rollout_fn, reward_fn, group=None, work_fn=None) -> torch.Tensor:
@@ -116,8 +180,11 @@ def sharded_candidate_rewards(actions: torch.Tensor, rollout_fn, reward_fn, grou
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     bounds = None
+    if actions.shape[0] < world:
+        raise ValueError(f"{actions.shape[0]} candidates cannot be sharded over {world} ranks (a rank would roll out nothing)")
     if work_fn is not None and world > 1:
         bounds = work_balanced_bounds(work_fn(actions), world)
+        bounds = bounds_of_rank0(bounds, group)              # work_fn runs per rank: one rank's cuts size the all-gather
         lo, hi = bounds[rank]
     else:
         lo, hi = shard_bounds(actions.shape[0], world, rank)

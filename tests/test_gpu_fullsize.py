@@ -288,3 +288,41 @@ def test_config4_mixed_variable_size_batch(ag, O, dev, material, cloud_fn, B):
                  lambda b: _oracle_trace(O, W, task, None, a_np[b], masked=(state[b], mask[b])),
                  lambda b: _per_step_masked(ag, m, dev, ppm, state[b], mask[b], a_np[b]), N,
                  fn_mask=lambda b: mask[b])
+
+
+def test_config4_as_one_mixed_call_equals_the_three_calls_bitwise(ag, O, dev):
+    """adaptigraph_amd.dynamics_mixed: the 172 rope + 170 granular + 170 cloth variable-size graphs of BASELINE configs[4] in ONE
+    entry (the three materials dealt to three streams, one read-back of all flags) - every material's rows equal the stand-alone
+    dynamics_masked call's (which the test above checks against the oracle), whatever runs beside them; an overflowing graph in
+    ONE material raises the reference's Exception("Exceeds max dims") out of the one entry."""
+    rng = np.random.default_rng(47)
+    batches, tight = [], []
+    for material, cloud_fn, B in (("rope", lambda r: _rope(300, r), 172), ("granular", lambda r: _grid(32, 0.12, 0.02, r), 170),
+                                  ("cloth", lambda r: _grid(45, 0.3, 0.02, r), 170)):
+        task = _task(material, max_nR=40000)
+        W, m = _model(ag, O, material, 47, dev)
+        cloud = cloud_fn(rng)
+        N = cloud.shape[0]
+        counts = rng.integers(N // 2, N + 1, B)
+        state = np.zeros((B, N, 3), np.float32)
+        mask = np.zeros((B, N), bool)
+        for b, c in enumerate(counts):
+            state[b, :c] = cloud[np.sort(rng.choice(N, c, replace=False))]
+            mask[b, :c] = True
+        a_np = _actions(cloud, B, 1, 20, rng, spread=1.5 if material != "rope" else 0.6)[:, 0]
+        a_np[1::5, 3] = 12.5
+        batches.append((torch.from_numpy(state).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(a_np), m, _ppm(task, material)))
+        small = _task(material, max_nR=40000 if material != "granular" else 500)           # granular's graphs have ~20,000 edges
+        tight.append(batches[-1][:4] + (_ppm(small, material),))
+    want = [ag.dynamics_masked(b[0], b[1], b[2], b[3], dev, b[4])["state_seqs"] for b in batches]
+    for pin in (None, True, False):
+        got = ag.dynamics_mixed(batches, dev, one_stream_each=pin)
+        assert len(got) == 3
+        for w, g_, b in zip(want, got, batches):
+            assert g_["state_seqs"].shape == w.shape and torch.equal(g_["state_seqs"], w), pin
+            assert g_["action_seqs"].shape == (b[0].shape[0], 4)
+    with pytest.raises(Exception, match="Exceeds max dims"):
+        ag.dynamics_mixed(tight, dev)
+    again = ag.dynamics_mixed(batches, dev)                              # the contexts are as good as before
+    assert all(torch.equal(g_["state_seqs"], w) for g_, w in zip(again, want))
+    assert ag.dynamics_mixed([], dev) == []

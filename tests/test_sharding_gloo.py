@@ -286,3 +286,85 @@ def test_gloo_work_balanced_rewards_match_unsharded():
             p.join(timeout=60)
             assert p.exitcode == 0
         assert res == [(r, True, True) for r in range(world)], res
+
+
+# ------------------------------------------------------------------------------------- r06: one rank's bounds, mixed batches
+def test_work_balanced_bounds_leave_no_rank_without_a_candidate():
+    from adaptigraph_amd.sharding import work_balanced_bounds
+    assert work_balanced_bounds(np.r_[1000.0, np.zeros(7)], 4) == [(0, 1), (1, 2), (2, 3), (3, 8)]      # one heavy head
+    assert work_balanced_bounds(np.r_[np.zeros(7), 1000.0], 4) == [(0, 5), (5, 6), (6, 7), (7, 8)]      # one heavy tail
+    for world in (2, 3, 8):
+        for n in (world, world + 1, 50):
+            b = work_balanced_bounds(np.random.default_rng(n).integers(0, 9, n), world)
+            assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:])) and all(hi > lo for lo, hi in b)
+
+
+def test_mixed_shard_bounds_cut_all_materials_at_once():
+    """BASELINE configs[4]: 172 rope + 170 granular + 170 cloth candidates with their own particle counts; a candidate's work
+    estimate is N_b x (topk + M) of its material.  One cut over the concatenated batch: every candidate lands on exactly one rank,
+    ranks carry about the same work, and a rank's piece may span materials."""
+    from adaptigraph_amd.sharding import mixed_shard_bounds
+    rng = np.random.default_rng(4)
+    spec = (("rope", 172, 300, 10 + 1), ("granular", 170, 1024, 20 + 5), ("cloth", 170, 2025, 5 + 1))
+    w = [rng.integers(N // 2, N + 1, B).astype(np.float64) * k for _, B, N, k in spec]
+    total = sum(x.sum() for x in w)
+    for world in (1, 2, 4, 8):
+        table = mixed_shard_bounds(w, world)
+        assert len(table) == world and all(len(row) == 3 for row in table)
+        for m, (_, B, _, _) in enumerate(spec):             # every batch is covered once, in rank order
+            spans = [row[m] for row in table]
+            assert spans[0][0] == 0 and spans[-1][1] == B and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        loads = np.array([sum(w[m][lo:hi].sum() for m, (lo, hi) in enumerate(row)) for row in table])
+        assert abs(loads.sum() - total) < 1e-6 and loads.max() - loads.min() <= 2 * max(x.max() for x in w) + 1e-6, (world, loads)
+    two = mixed_shard_bounds(w, 2)
+    assert two[0][0] == (0, 172) and two[0][1][1] > 0 and two[1][0] == (172, 172)      # rank 0: all the rope and some granular
+    # count-balanced per material (what sharding each material separately by count would give) is visibly worse
+    per_count = np.array([sum(w[m][lo:hi].sum() for m, (lo, hi) in enumerate([shard_bounds(B, 8, r) for _, B, _, _ in spec])) for r in range(8)])
+    eight = mixed_shard_bounds(w, 8)
+    loads8 = np.array([sum(w[m][lo:hi].sum() for m, (lo, hi) in enumerate(row)) for row in eight])
+    assert loads8.max() / loads8.mean() <= per_count.max() / per_count.mean() + 1e-9
+
+
+def _mixed_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adaptigraph_amd.sharding import sharded_mixed_values, sharded_candidate_rewards, mixed_shard_bounds
+    rng = np.random.default_rng(6)                         # every rank builds the same inputs
+    sizes, scale = (23, 17, 19), (11.0, 25.0, 6.0)
+    counts = [rng.integers(5, 40, n) for n in sizes]
+    w = [c.astype(np.float64) * k for c, k in zip(counts, scale)]
+    states = [torch.from_numpy(rng.normal(size=(n, 40, 3)).astype(np.float32)) for n in sizes]
+    seen = []
+
+    def evaluate_rows(m, lo, hi):                          # stands in for dynamics_masked + a per-candidate cost: row-wise
+        seen.append((m, lo, hi))
+        return (states[m][lo:hi] * (m + 1)).sum((1, 2))
+
+    got = sharded_mixed_values(w, evaluate_rows)
+    want = [(states[m] * (m + 1)).sum((1, 2)) for m in range(3)]
+    ok = all(torch.equal(g_, w_) for g_, w_ in zip(got, want))
+    ok = ok and seen == [(m, lo, hi) for m, (lo, hi) in enumerate(mixed_shard_bounds(w, world)[rank]) if hi > lo]
+    # a work estimate that differs between the ranks (per-context state) must not desynchronise the all-gather: rank 0's cuts serve
+    torch.manual_seed(0)
+    actions = torch.rand(31, 2, 4)
+    work_fn = lambda a: np.arange(31) % (3 + rank)         # a different estimate on every rank
+    full = sharded_candidate_rewards(actions, lambda a: a.sum(-1, keepdim=True).repeat(1, 1, 5), lambda seq, a: seq[:, -1].mean(-1),
+                                     work_fn=work_fn)
+    ok = ok and torch.equal(full, actions.sum(-1, keepdim=True).repeat(1, 1, 5)[:, -1].mean(-1))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gloo_mixed_batch_values_and_rank0_bounds():
+    ctx = mp.get_context("spawn")
+    for world in (2, 4):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_mixed_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert res == [(r, True) for r in range(world)], res

@@ -160,7 +160,7 @@ def mixed(total, steps, reps, report=True):
     """cfg 5: a third of the batch per material, every candidate with its own particle count U{N/2..N} (padded + masked);
     dynamics_masked advances one look-ahead step of `steps` repeats."""
     rng = np.random.default_rng(1)
-    calls, n_steps, engines, enc_fwd, node_fwd, edge_fwd = [], 0, [], 0, 0, 0
+    calls, batches, n_steps, engines, enc_fwd, node_fwd, edge_fwd = [], [], 0, [], 0, 0, 0
     for mat, nb in (("rope", total // 3 + total % 3), ("granular", total // 3), ("cloth", total // 3)):
         cloud = cloud_of(mat, rng)
         N = cloud.shape[0]
@@ -173,6 +173,7 @@ def mixed(total, steps, reps, report=True):
         a = B.make_actions(nb, 1, steps, cloud, rng)[:, 0]
         args = (torch.from_numpy(state).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(a).to(dev))
         calls.append(lambda args=args, m=m, ppm=ppm: ag.dynamics_masked(*args, m, dev, ppm))
+        batches.append((args[0], args[1], torch.from_numpy(a), m, ppm))      # (CPU-resident pushes: no read-back inside the call)
         n_steps += nb * steps
         engines.append(m.engine(dev))
         if report:
@@ -184,9 +185,19 @@ def mixed(total, steps, reps, report=True):
             edge_fwd += E * steps
             node_fwd += (int(mask.sum()) + nb * task["eef_num"]) * steps
     fn = lambda: [c() for c in calls]
-    dt = timed(fn, reps)
+    fn_mixed = lambda: ag.dynamics_mixed(batches, dev)
+    seq_out, mix_out = fn(), fn_mixed()
+    same = all(torch.equal(a_["state_seqs"], b_["state_seqs"]) for a_, b_ in zip(seq_out, mix_out))
+    dt_seq = timed(fn, reps)
+    dt_seq_cpu = timed(lambda: [ag.dynamics_masked(b_[0], b_[1], b_[2], b_[3], dev, b_[4]) for b_ in batches], reps)
+    dt_pin = timed(lambda: ag.dynamics_mixed(batches, dev, one_stream_each=True), reps)
+    dt_fork = timed(lambda: ag.dynamics_mixed(batches, dev, one_stream_each=False), reps)
+    dt = timed(fn_mixed, reps)
     out = {"config": f"mixed rope+granular+cloth, {total} variable-size graphs x {steps} steps", "ms_per_call": dt * 1e3,
-           "rollout_steps_per_s": n_steps / dt}
+           "rollout_steps_per_s": n_steps / dt, "entry": "adaptigraph_amd.dynamics_mixed (three materials dealt to three streams, one read-back)",
+           "ms_three_sequential_dynamics_masked_calls": dt_seq * 1e3, "ms_three_sequential_calls_cpu_resident_pushes": dt_seq_cpu * 1e3,
+           "ms_dynamics_mixed_engines_on_one_stream_each": dt_pin * 1e3, "ms_dynamics_mixed_engines_fork_by_size": dt_fork * 1e3,
+           "bit_equal_to_the_sequential_calls": bool(same)}
     if report:
         out.update(kernel_report(engines, fn, enc_fwd, node_fwd, dt * 1e3, edge_fwd))
     return out

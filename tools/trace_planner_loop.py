@@ -36,11 +36,11 @@ def report(d):
     api = [(int(a["Start_Timestamp"]), int(a["End_Timestamp"]), a["Function"]) for a in api]
     api.sort()
     samples = [k for k in ker if "k_mppi_sample" in k[2]]
-    n_iter = int(os.environ.get("AG_TRACE_ITERS", "40"))
     meta = {}
     mp = os.path.join(d, "run_meta.json")
     if os.path.exists(mp):
         meta = json.load(open(mp))
+    n_iter = int(os.environ.get("AG_TRACE_ITERS", meta.get("sample_kernels_per_call", 40)))
     mode = meta.get("mode", "loop")
     if mode.startswith("chunked"):
         # all 40 chunks are sampled back to back, then ONE rollout call: the call starts at the 40th-last sampling kernel
@@ -50,6 +50,7 @@ def report(d):
         t_begin = samples[-n_iter][0]
         cuts = [s[0] for s in samples[-n_iter:]] + [ker[-1][1] + 1]
     per = []
+    blk_n = {}
     for i in range(len(cuts) - 1):
         a, b = cuts[i], cuts[i + 1]
         ks = [k for k in ker if a <= k[0] < b]
@@ -67,6 +68,7 @@ def report(d):
         for s, e, f in api:
             if a <= s < b and f in BLOCKING:
                 blk[f] = blk.get(f, 0) + (e - s)
+                blk_n[f] = blk_n.get(f, 0) + 1
         by_k = {}
         for s, e, n, _ in ks:
             by_k[n] = by_k.get(n, 0) + (e - s)
@@ -105,6 +107,9 @@ def report(d):
            "kernel_ms_by_queue_and_stream": {k: v / 1e6 for k, v in by_q.items()},
            "host_hip_api_calls_top_ms": {k: {"calls": v[0], "ms": v[1]} for k, v in api_top.items()},
            "host_blocked_ms": {k: v / 1e3 for k, v in blk.items()},
+           # blocking HIP calls the host made between the first sampling kernel of the call and its last kernel (merge_res's one
+           # read-back included): hipStreamSynchronize / hipEventSynchronize / hipMemcpy* / hipDeviceSynchronize
+           "host_blocking_calls": blk_n, "host_blocking_calls_total": int(sum(blk_n.values())),
            "per_iteration_median_us": {k: float(np.median([p[k] for p in per])) for k in ("wall_us", "gpu_busy_us", "gpu_idle_us", "kernels")},
            "kernel_time_ms_top": {k: v / 1e3 for k, v in top.items()},
            "example_iteration": per[len(per) // 2] if per else None}
@@ -118,16 +123,27 @@ def run(mat, mode):
     import bench_planner as BP
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(0)
-    planner, m, s0, lo, hi, cloud, task = BP.make_planner(mat, 500, rng)
+    n_chunk, per_call = 40, 40
+    if mode.startswith("interact"):
+        # random_interact.py:155-214: n_update_iter 5, n_sample 1000; interact1 = its n_sample_chunk 1000 (ONE call per planner call),
+        # interact2 = two chunks of 500; suffix _strict = every rollout waited for, winners re-rolled (the r04 behaviour)
+        import bench_interact as BI
+        n_chunk = 1 if mode.startswith("interact1") else 2
+        planner, m, s0, lo, hi, cloud, task = BI.make_interact_planner(mat, 1000 // n_chunk, rng)
+        per_call = n_chunk * planner.n_update_iter
+        if mode.endswith("_strict"):
+            planner.pipeline_chunks, planner.reuse_best_rollout = 0, False
+    else:
+        planner, m, s0, lo, hi, cloud, task = BP.make_planner(mat, 500, rng)
     torch.manual_seed(0)
     act_seq = torch.rand((1, 4), device=dev) * (hi - lo) + lo
     if mode == "loop_r04":                                  # one stream, every call waits, winners re-rolled
         planner.pipeline_chunks, planner.reuse_best_rollout = 0, False
     elif mode == "loop_nopipe":
         planner.pipeline_chunks = 0
-    elif mode not in ("loop", "chunked"):
-        raise SystemExit("mode: loop | loop_r04 | loop_nopipe | chunked")
-    fn = (lambda: BP.loop_call(planner, s0, act_seq, 40)) if mode.startswith("loop") else \
+    elif mode not in ("loop", "chunked") and not mode.startswith("interact"):
+        raise SystemExit("mode: loop | loop_r04 | loop_nopipe | chunked | interact1[_strict] | interact2[_strict]")
+    fn = (lambda: BP.loop_call(planner, s0, act_seq, n_chunk)) if not mode.startswith("chunked") else \
          (lambda: planner.trajectory_optimization_chunked(s0, act_seq, 40))
     import time
     for _ in range(2):
@@ -139,7 +155,7 @@ def run(mat, mode):
     res = fn()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    meta = {"material": mat, "mode": mode, "traced_call_ms_host_clock": dt * 1e3,
+    meta = {"material": mat, "mode": mode, "traced_call_ms_host_clock": dt * 1e3, "sample_kernels_per_call": per_call,
             "best_reward": float(res["best_eval_output"]["reward_seqs"].mean())}
     out_dir = os.environ.get("AG_TRACE_META_DIR")
     if out_dir:
