@@ -221,28 +221,34 @@ def construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=10, co
 
 
 def construct_edges_with_backoff(states, adj_thresh, mask, tool_mask, topk, max_nR, knn_thresh=1.0, min_kNN=1.0,
-                                 knn_increment=0.1, **rules):
+                                 knn_increment=0.1, as_index=False, trail=None, **rules):
     """The max_nR back-off loop the reference repeats around construct_edges_from_states (rollout.py:173-222,
     rollout/graph.py:508-543, dataset.py:310-350): if the graph does not fit max_nR, first shrink the tool's kNN
     fraction by knn_increment down to min_kNN, then lower top-k by one per attempt.  `rules` are the remaining keyword
-    arguments of construct_edges_from_states (connect_tools_all, max_y, ...).  Returns (Rr, Rs) padded to max_nR."""
-    Rr, Rs = construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=topk, kNN=knn_thresh, **rules)
+    arguments of construct_edges_from_states (connect_tools_all, max_y, ...).  Returns (Rr, Rs) padded to max_nR, or with
+    as_index the EdgeList of the graph that fitted (the fit test is then one integer read per attempt instead of the dense
+    pad_torch).  trail (list): receives (kNN, topk, n_rel) of every attempt."""
     kNN = knn_thresh
     decrease_topK = topk
+    k_now = topk
     while True:
-        try:
-            return pad_torch(Rr, max_nR), pad_torch(Rs, max_nR)                          # rollout.py:192-194
-        except Exception as e:
-            if str(e) != "Exceeds max dims":
-                raise
-            if kNN <= min_kNN:                                                          # rollout.py:199-211
-                decrease_topK = decrease_topK - 1
-                if decrease_topK < 1:
-                    raise
-                Rr, Rs = construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=decrease_topK, kNN=kNN, **rules)
-            else:                                                                       # rollout.py:212-222
-                kNN = kNN - knn_increment
-                Rr, Rs = construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=topk, kNN=kNN, **rules)
+        el = construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=k_now, kNN=kNN, as_index=True, **rules)
+        n_rel = int(el.n_edges[0].item())
+        if trail is not None:
+            trail.append((float(kNN), int(k_now), n_rel))
+        if n_rel <= max_nR:                                                             # rollout.py:192-194 pad_torch fits
+            if as_index:
+                return el
+            Rr, Rs = el.to_dense(n_rel)
+            return pad_torch(Rr[0], max_nR), pad_torch(Rs[0], max_nR)
+        if kNN <= min_kNN:                                                              # rollout.py:199-211
+            decrease_topK = decrease_topK - 1
+            if decrease_topK < 1:
+                raise Exception("Exceeds max dims")                                     # (the reference would loop on: utils.py:63-65)
+            k_now = decrease_topK
+        else:                                                                           # rollout.py:212-222
+            kNN = kNN - knn_increment
+            k_now = topk
 
 
 def pad_torch(x, max_dim, dim=0):

@@ -497,6 +497,66 @@ def rollout_work(W, pstep, state, action, task, physics_param=0.5):
 
 
 # --------------------------------------------------------------------------- helpers shared by tests / bench
+# --------------------------------------------------------------------------- eval open-loop rollout step
+def surface_bounds(obj_kp, ratio):
+    """rollout.py:132-139 on numpy float32 scalars, as written there."""
+    obj_kp = np.asarray(obj_kp, F32)
+    max_y = np.max(obj_kp[:, 1]) * ratio
+    min_y = np.min(obj_kp[:, 1])
+    max_x = np.max(obj_kp[:, 0]) * ratio
+    max_z = np.max(obj_kp[:, 2]) * ratio
+    min_x = np.min(obj_kp[:, 0])
+    min_x = (max_x - min_x) * (1 - ratio) + min_x
+    min_z = np.min(obj_kp[:, 2])
+    min_z = (max_z - min_z) * (1 - ratio) + min_z
+    return dict(max_y=max_y, min_y=min_y, max_x=max_x, max_z=max_z, min_x=min_x, min_z=min_z)
+
+
+def edges_with_backoff(pos, cfg, mask, tool_mask, bounds, trail=None):
+    """construct_edges_from_states + the max_nR back-off of rollout.py:168-222: kNN down by knn_increment to min_kNN, then
+    top-k down by one per attempt.  cfg: the dataset entries rollout.py:27-51 reads.  trail: (kNN, topk, n_rel) per attempt."""
+    kw = dict(connect_tools_all=cfg["connect_tool_all"], connect_tools_surface=cfg["connect_tool_surface"],
+              connect_tool_all_non_fixed=cfg["connect_tool_all_non_fixed"], **bounds)
+    kNN, dec, k_now = cfg["knn_thresh"], cfg["topk"], cfg["topk"]
+    while True:
+        r, s = construct_edges_from_states(pos, cfg["adj_thresh"], mask, tool_mask, topk=k_now, kNN=kNN, **kw)
+        if trail is not None:
+            trail.append([float(kNN), int(k_now), len(r)])
+        if len(r) <= cfg["max_nR"]:                                                       # :192-194 pad_torch fits
+            return r, s
+        if kNN <= cfg["min_kNN"]:                                                         # :199-211
+            dec = dec - 1
+            k_now = dec
+        else:                                                                             # :212-222
+            kNN = kNN - cfg["knn_increment"]
+            k_now = cfg["topk"]
+
+
+def eval_rollout_step(W, pstep, graph, eef_start, eef_end, cfg, trail=None):
+    """One iteration of rollout_from_start_graph's loop (rollout.py:108-260) without its dataset side.  graph (numpy, one graph):
+    'state' (n_his,N+M,3), 'action' (N+M,3), 'attrs' (N+M,2), 'edges' (recv, send), 'p_instance' (N,n_inst), 'physics' (N,),
+    'obj_mask' (N,), 'state_mask', 'eef_mask' (N+M,).  -> (next graph, pred_state (N,3), pred_motion (N,3))."""
+    n_p = graph["p_instance"].shape[0]
+    pos, mot = model_forward(W, graph["state"][None], graph["attrs"][None], [graph["edges"]], graph["p_instance"][None],
+                             graph["action"][None], graph["physics"][None], pstep)         # :112
+    pred = pos[0]
+    obj_kp = pred[graph["obj_mask"]]                                                      # :121
+    bounds = surface_bounds(obj_kp, cfg["connect_tool_surface_ratio"])                    # :132-139
+    states = np.concatenate([pred, np.asarray(eef_start, F32)], 0).astype(F32)            # :163
+    delta = np.zeros_like(states)
+    delta[n_p:n_p + len(eef_start)] = np.asarray(eef_end, F32) - np.asarray(eef_start, F32)   # :165-166
+    edges = edges_with_backoff(states, cfg, graph["state_mask"], graph["eef_mask"], bounds, trail)
+    hist = graph["state"]
+    if cfg.get("store_rest_state"):
+        hist = np.concatenate([hist[:1], hist[2:], states[None]], 0)                      # :224-229 the rest frame stays
+    else:
+        hist = np.concatenate([hist[1:], states[None]], 0)                                # :231-232
+    nxt = dict(graph)
+    nxt.update(state=hist.astype(F32), action=delta, edges=edges)
+    return nxt, pred, mot[0]
+
+
+# --------------------------------------------------------------------------- weights
 def weights_from_npz(npz):
     return {k[3:]: np.asarray(npz[k], F32) for k in npz.files if k.startswith("w::")}
 

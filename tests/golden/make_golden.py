@@ -433,7 +433,7 @@ def main():
         time_reference(refs)
 
 
-if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5", "--planner", "--fullsize", "--fullsize-more", "--fullsize-r05", "--nhis5-rollout"} & set(sys.argv)):
+if __name__ == "__main__" and not ({"--costs", "--ppm", "--mppi", "--single", "--single-rules", "--masked-more", "--nhis5", "--planner", "--fullsize", "--fullsize-more", "--fullsize-r05", "--nhis5-rollout", "--eval-rollout"} & set(sys.argv)):
     main()
 
 # dynamics_masked for the other two materials: gripper offset + connect_tools_all (cloth) and the 5-point pusher
@@ -1143,3 +1143,156 @@ if __name__ == "__main__" and "--fullsize-r05" in sys.argv:
         gen_fullsize_granular_more()
     if "cloth" in sys.argv or "all" in sys.argv:
         gen_fullsize_seqs("full_cloth_seqs")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# r06, SURVEY 8(f) rank 3 completed: the EVAL open-loop rollout (src/dynamics/rollout/rollout.py:108-260).  The reference's OWN
+# functions - model(**graph), truncate_graph, construct_edges_from_states, pad_torch - are called in the order of that loop on
+# the softbody configuration (config/dynamics/softbody.yaml: n_his 5, pstep 4, store_rest_state, connect_tool_all_non_fixed,
+# knn_range [0.4, 1.0], min_knn 0.4, knn_increment 0.1): a cube cloud of 216 particles padded to max_nobj 230, a five-point
+# flat pusher that comes down onto it and then drags sideways.  rollout.py's dataset side (ground truth, errors, viz) is not
+# driven: the tool keypoints come from a synthetic trajectory.  max_nR is chosen so that some steps fit at once, some need the
+# kNN back-off only and some lower top-k as well.  Stored per step: the cloud the builder was fed, the final edge list, the
+# back-off trail, the prediction; the initial graph; weights.  Data only.
+def gen_eval_rollout(name, n_steps=12):
+    DynamicsPredictor = import_reference()[0]
+    from dynamics.dataset.graph import construct_edges_from_states
+    from dynamics.utils import pad_torch, truncate_graph
+    with open(f"{REF}/config/dynamics/softbody.yaml") as f:
+        dyn = yaml.safe_load(f)
+    ds = dyn["dataset_config"]["datasets"][0]
+    n_his, store_rest = dyn["dataset_config"]["n_his"], dyn["dataset_config"]["store_rest_state"]
+    assert n_his == 5 and store_rest and dyn["model_config"]["pstep"] == 4
+    adj_thresh = (ds["adj_radius_range"][0] + ds["adj_radius_range"][1]) / 2            # rollout.py:33
+    topk = ds["topk"]
+    knn_thresh = (ds["knn_range"][0] + ds["knn_range"][1]) / 2                          # :35
+    min_kNN, knn_increment = ds["min_knn"], ds["knn_increment"]
+    cta, nonfixed = ds["connect_tool_all"], ds["connect_tool_all_non_fixed"]
+    surface, ratio = ds["connect_tool_surface"], ds["connect_tool_surface_ratio"]
+    model = make_model(DynamicsPredictor, dyn, 21)
+    rng = np.random.default_rng(21)
+    side, pitch = 6, 0.2
+    g = (np.arange(side) * pitch).astype(np.float32)
+    xx, yy, zz = np.meshgrid(g, g, g, indexing="ij")
+    cube = (np.stack([xx.ravel(), yy.ravel(), zz.ravel()], 1) + rng.normal(0, 0.01, (side ** 3, 3))).astype(np.float32)
+    cube = cube[rng.permutation(len(cube))]                                              # (no index / position coherence)
+    n_kp, max_nobj, M = len(cube), 230, 5
+    N = max_nobj + M
+    tool0 = np.float32([[0.5, 0.0, 0.5], [0.2, 0.0, 0.5], [0.8, 0.0, 0.5], [0.5, 0.0, 0.2], [0.5, 0.0, 0.8]])
+    T = n_steps + n_his + 2
+    eef_pos = np.zeros((T, M, 3), np.float32)
+    for t in range(T):
+        down = min(t, 10) * 0.06                                                         # comes down for ten frames ...
+        drag = max(0, t - 10) * 0.05                                                     # ... then drags along +x
+        eef_pos[t] = tool0 + np.float32([drag, 1.62 - down, 0.0])
+    obj_mask = np.zeros(max_nobj, bool); obj_mask[:n_kp] = True
+    state_mask = np.zeros(N, bool); state_mask[:n_kp] = True; state_mask[max_nobj:] = True
+    eef_mask = np.zeros(N, bool); eef_mask[max_nobj:] = True
+    attrs = np.zeros((N, 2), np.float32); attrs[:n_kp, 0] = 1; attrs[max_nobj:, 1] = 1
+    p_instance = np.zeros((max_nobj, 1), np.float32); p_instance[:n_kp, 0] = 1
+    phys = np.zeros(max_nobj, np.float32); phys[:n_kp] = rng.uniform(0.2, 0.8, n_kp).astype(np.float32)   # per-particle stiffness
+    hist = np.zeros((n_his, N, 3), np.float32)
+    for h in range(n_his):
+        hist[h, :n_kp] = cube
+        hist[h, max_nobj:] = eef_pos[h]
+    tm, te = torch.from_numpy(state_mask), torch.from_numpy(eef_mask)
+
+    def bounds_of(obj):                                                                  # rollout.py:132-139 on numpy float32 scalars
+        max_y = np.max(obj[:, 1]) * ratio
+        min_y = np.min(obj[:, 1])
+        max_x = np.max(obj[:, 0]) * ratio
+        max_z = np.max(obj[:, 2]) * ratio
+        min_x = np.min(obj[:, 0])
+        min_x = (max_x - min_x) * (1 - ratio) + min_x
+        min_z = np.min(obj[:, 2])
+        min_z = (max_z - min_z) * (1 - ratio) + min_z
+        return dict(max_y=max_y, min_y=min_y, max_x=max_x, max_z=max_z, min_x=min_x, min_z=min_z)
+
+    def build(states, b, max_nR):
+        """construct_edges_from_states + the pad_torch back-off of rollout.py:168-222 (graph.py:508-543 for the first graph)"""
+        kw = dict(mask=tm, tool_mask=te, connect_tools_all=cta, connect_tools_surface=surface, connect_tool_all_non_fixed=nonfixed, **b)
+        ts = torch.from_numpy(states)
+        assert_no_topk_boundary_tie(ts[None], tm[None], te[None], adj_thresh, topk)
+        Rr, Rs = quiet(construct_edges_from_states, ts, adj_thresh, topk=topk, kNN=knn_thresh, **kw)
+        kNN, dec = knn_thresh, topk
+        trail = [[float(kNN), int(topk), int(Rr.shape[0])]]
+        while True:
+            try:
+                return pad_torch(Rr, max_nR), pad_torch(Rs, max_nR), trail
+            except Exception:
+                if kNN <= min_kNN:
+                    dec = dec - 1
+                    Rr, Rs = quiet(construct_edges_from_states, ts, adj_thresh, topk=dec, kNN=kNN, **kw)
+                    trail.append([float(kNN), int(dec), int(Rr.shape[0])])
+                else:
+                    kNN = kNN - knn_increment
+                    Rr, Rs = quiet(construct_edges_from_states, ts, adj_thresh, topk=topk, kNN=kNN, **kw)
+                    trail.append([float(kNN), int(topk), int(Rr.shape[0])])
+
+    def run(max_nR):
+        Rr, Rs, trail0 = build(hist[-1], bounds_of(cube), max_nR)
+        action0 = np.zeros((N, 3), np.float32)
+        action0[max_nobj:] = eef_pos[n_his] - eef_pos[n_his - 1]
+        graph = {"state": torch.from_numpy(hist)[None], "action": torch.from_numpy(action0)[None], "Rr": Rr[None], "Rs": Rs[None],
+                 "attrs": torch.from_numpy(attrs)[None], "p_rigid": torch.zeros(1, 1), "p_instance": torch.from_numpy(p_instance)[None],
+                 "obj_mask": torch.from_numpy(obj_mask)[None], "eef_mask": te[None], "state_mask": tm[None],
+                 "material_index": torch.ones(1, max_nobj, 1, dtype=torch.long), "softbody_physics_param": torch.from_numpy(phys)[None]}
+        first = {"Rr": Rr, "Rs": Rs, "trail": trail0, "action": action0}
+        steps = []
+        for i in range(1, n_steps + 1):
+            with torch.no_grad():
+                graph = truncate_graph(graph)                                            # rollout.py:111
+                pred_state, pred_motion = quiet(model, **graph)                           # :112
+            pred = pred_state.numpy()
+            obj_kp = pred[0][obj_mask]                                                    # :121
+            b = bounds_of(obj_kp[:n_kp])                                                  # :127-139
+            t0, t1 = n_his - 1 + i, n_his + i                                             # the next frame pair
+            states = np.concatenate([pred[0], eef_pos[t0]], 0)                            # :163
+            delta = np.zeros_like(states); delta[max_nobj:max_nobj + M] = eef_pos[t1] - eef_pos[t0]   # :165-166
+            Rr, Rs, trail = build(states, b, max_nR)                                      # :168-222
+            sh = graph["state"][0].numpy()
+            tail = np.concatenate([sh[2:], states[None]], 0)                              # :227-229 (store_rest_state)
+            sh = np.concatenate([sh[:1], tail], 0)
+            new = {"state": torch.from_numpy(sh)[None].float(), "action": torch.from_numpy(delta)[None].float(),
+                   "Rr": Rr[None].float(), "Rs": Rs[None].float()}
+            for k in ("attrs", "p_rigid", "p_instance", "obj_mask", "eef_mask", "state_mask", "material_index", "softbody_physics_param"):
+                new[k] = graph[k]
+            graph = new
+            steps.append({"pred": pred[0].copy(), "motion": pred_motion.numpy()[0].copy(), "states": states.astype(np.float32), "edges": edges_from_R(Rr[None], Rs[None])[0],
+                          "trail": trail, "bounds": {k: float(v) for k, v in b.items()}, "eef_start": eef_pos[t0], "eef_end": eef_pos[t1]})
+        return first, steps
+
+    pick = None
+    for max_nR in (2527, 2528, 2526, 2525, 2560, 2520, 2600):
+        first, steps = run(max_nR)
+        kinds = set()
+        for st in steps:
+            tr = st["trail"]
+            kinds.add("fits" if len(tr) == 1 else "topk" if tr[-1][1] < topk else "knn")
+        print(f"  max_nR {max_nR}: " + " ".join(f"{len(st['trail']) - 1}:{st['trail'][-1][2]}" for st in steps), kinds)
+        if kinds == {"fits", "knn", "topk"}:
+            pick = max_nR
+            break
+    assert pick is not None, "no max_nR gives all three back-off regimes; change the scenario"
+    store = weights_npz(model)
+    store.update(hist0=hist, action0=first["action"], attrs=attrs, p_instance=p_instance, physics_param=phys, obj_mask=obj_mask,
+                 state_mask=state_mask, eef_mask=eef_mask, eef_pos=eef_pos, pstep=np.int32(4), n_his=np.int32(5))
+    pack_edges("first::", [edges_from_R(first["Rr"][None], first["Rs"][None])[0]], store)
+    store["pred_pos"] = np.stack([st["pred"] for st in steps])                              # (S, max_nobj, 3)
+    store["pred_motion"] = np.stack([st["motion"] for st in steps])
+    store["builder_states"] = np.stack([st["states"] for st in steps])                      # (S, N, 3)
+    store["eef_start"] = np.stack([st["eef_start"] for st in steps]); store["eef_end"] = np.stack([st["eef_end"] for st in steps])
+    pack_edges("step::", [st["edges"] for st in steps], store)
+    meta = {"adj_thresh": adj_thresh, "topk": topk, "knn_thresh": knn_thresh, "min_kNN": min_kNN, "knn_increment": knn_increment,
+            "connect_tool_all": cta, "connect_tool_all_non_fixed": nonfixed, "connect_tool_surface": surface,
+            "connect_tool_surface_ratio": ratio, "max_nR": int(pick), "max_nobj": max_nobj, "store_rest_state": True,
+            "first_trail": first["trail"], "trails": [st["trail"] for st in steps], "bounds_f32": [st["bounds"] for st in steps],
+            "numpy": np.__version__, "torch": torch.__version__}
+    store["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **store)
+    print(f"{name}: max_nR {pick}, {n_steps} steps, back-off attempts per step {[len(st['trail']) - 1 for st in steps]} -> {os.path.getsize(path)/1e6:.2f} MB")
+
+
+if __name__ == "__main__" and "--eval-rollout" in sys.argv:
+    gen_eval_rollout("eval_rollout_softbody")
