@@ -209,6 +209,16 @@ void slot_release(CallSlot* s, hipStream_t st, bool capturing) {
     if (capturing || !s || !s->ev_done) return;
     if (hipEventRecord(s->ev_done, st) == hipSuccess) s->have_done = true;
 }
+// Records the slot's end-of-call event on EVERY exit of the call that acquired it (r06): an early `return rc` after work was
+// enqueued used to leave ev_done marking an EARLIER call, so a later take-over of the slot by another stream (slot_acquire's LRU
+// path, the wait-for-all-slots before d_base_cache is replaced) would not have waited for what the failed call had enqueued.
+struct SlotGuard {
+    CallSlot* s; hipStream_t st; bool capturing;
+    SlotGuard(CallSlot* s_, hipStream_t st_, bool cap_) : s(s_), st(st_), capturing(cap_) {}
+    SlotGuard(const SlotGuard&) = delete;
+    SlotGuard& operator=(const SlotGuard&) = delete;
+    ~SlotGuard() { slot_release(s, st, capturing); }
+};
 // is a call of another slot still running on the GPU?  (then this caller is pipelining calls over streams)
 bool other_slot_busy(ag_ctx* c, const CallSlot* me) {
     bool busy = false;
@@ -483,7 +493,9 @@ int pick_slices(const ag_ctx* c, int B, int N) {
     // a slice is at least 16 rows (one per wavefront of the workgroup): small batches are latency-bound, so a single
     // graph is spread over as many workgroups as that allows (one rope graph: 4 -> 18 workgroups, 43 -> 13 us per launch)
     s = std::min(s, std::max(1, N / 16));
-    return std::max(1, std::min(s, 64));
+    // (r06: up to 128 slices - one cloth-sized graph alone was cut into 64 slices of 32 rows, two rows per wavefront on a quarter
+    // of the chip; 127 slices of 16 rows give every wavefront one row.  Which rows share a workgroup never changes a row's result.)
+    return std::max(1, std::min(s, 128));
 }
 
 // the gather (ag_mlp.hip: gather_agg) addresses C, U and V with 32-bit element offsets: a launch chunk must keep every buffer below 2^32 floats
@@ -789,6 +801,7 @@ int ag_build_edges(ag_ctx* c, void* stream, const float* d_pos, const uint8_t* d
     CallSlot* sl = nullptr;
     rc = slot_acquire(c, st, false, &sl);
     if (rc) return rc;
+    SlotGuard slot_guard(sl, st, false);
     rc = ensure_slab(c, *sl, rows * (size_t)(ell_stride + 1) * 4 + (size_t)B * (slices + 1) * 4 + 4096);
     if (rc) return rc;
     EdgeArgs a{};
@@ -802,7 +815,6 @@ int ag_build_edges(ag_ctx* c, void* stream, const float* d_pos, const uint8_t* d
     a.max_nR = edge_cap; a.zero_on_overflow = 0; a.block_min_rows = c->opt.edge_block_min;
     c->prof_stream = st;
     HIPCHK(c, launch_edge_build(a, st, prof_mark, c));
-    slot_release(sl, st, false);
     return AG_OK;
 }
 
@@ -822,6 +834,7 @@ int ag_build_edges_single(ag_ctx* c, void* stream, const float* d_pos, const uin
     CallSlot* sl = nullptr;
     rc = slot_acquire(c, st, false, &sl);
     if (rc) return rc;
+    SlotGuard slot_guard(sl, st, false);
     rc = ensure_slab(c, *sl, (size_t)N * (size_t)(ell_stride + 1) * 4 + (size_t)(slices + 1) * 4 + 4096);
     if (rc) return rc;
     EdgeArgs a{};
@@ -836,7 +849,6 @@ int ag_build_edges_single(ag_ctx* c, void* stream, const float* d_pos, const uin
     a.max_nR = edge_cap; a.zero_on_overflow = 0; a.block_min_rows = c->opt.edge_block_min;
     c->prof_stream = st;
     HIPCHK(c, launch_edge_build(a, st, prof_mark, c));
-    slot_release(sl, st, false);
     return AG_OK;
 }
 
@@ -858,6 +870,7 @@ int ag_edges_apply_tool_rule(ag_ctx* c, void* stream, const float* d_pos, const 
     CallSlot* sl = nullptr;
     int rc = slot_acquire(c, st, false, &sl);
     if (rc) return rc;
+    SlotGuard slot_guard(sl, st, false);
     rc = ensure_slab(c, *sl, pairs * 6 + (size_t)(N + n_tools + 16) * 4 + 8 * 256);
     if (rc) return rc;
     RuleArgs a{};
@@ -871,7 +884,6 @@ int ag_edges_apply_tool_rule(ag_ctx* c, void* stream, const float* d_pos, const 
     a.deg = sl->slab.take<int>(N);
     a.recv = d_recv; a.send = d_send; a.row_ptr = d_row_ptr; a.n_out = d_n_out;
     HIPCHK(c, launch_tool_rule(a, st));
-    slot_release(sl, st, false);
     return AG_OK;
 }
 
@@ -895,6 +907,7 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
     CallSlot* sl = nullptr;
     int rc = slot_acquire(c, st, false, &sl);
     if (rc) return rc;
+    SlotGuard slot_guard(sl, st, false);
     rc = ensure_slab(c, *sl, work_bytes(Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0) + (size_t)B * 4 + 512);
     if (rc) return rc;
     rc = carve_work(c, sl->slab, w, Bc, N, n_inst, edge_cap, c_cap, 1, false, false, false, n_p, 0);
@@ -921,7 +934,6 @@ int ag_forward(ag_ctx* c, void* stream, const float* d_state, const float* d_att
     int seen = 0;
     HIPCHK(c, hipMemcpyAsync(&seen, sl->d_words, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    slot_release(sl, st, false);
     if (seen > 0) return fail(c, AG_ERR_MAX_NR, "Exceeds max dims: a graph had %d edges, edge_cap=%d", seen, edge_cap);
     return AG_OK;
 }
@@ -975,6 +987,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
     rc = slot_acquire(c, st, capturing, &slp);
     if (rc) return rc;
     CallSlot& sl = *slp;
+    SlotGuard slot_guard(slp, st, capturing);                // (a captured event could not be waited for outside its graph)
     c->last_slot = (int)(slp - c->slots);
     c->d_share_nns = nullptr;                                // pointed into a workspace of an earlier call
     if (d_state_seqs) HIPCHK(c, hipMemsetAsync(d_state_seqs, 0, (size_t)p->B * p->H * p->N_o * 3 * 4, st));   // forward_dynamics.py:32
@@ -1425,7 +1438,6 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             src.h_work[b] = (int32_t)w;
         }
         c->d_plan_sums = nullptr;
-        slot_release(&sl, st, capturing);
         return AG_OK;
     }
     hipStream_t streams[ag_ctx::kMaxStreams] = {st, st, st, st};
@@ -1560,7 +1572,6 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             rc_join = fail(c, AG_ERR_HIP, "joining stream %d failed: %s", i, hipGetErrorString(e));
     }
     c->prof_stream = st;
-    slot_release(&sl, st, capturing);                        // (a captured event could not be waited for outside its graph)
     return rc_loop ? rc_loop : rc_join;
 }
 }  // namespace
@@ -1590,12 +1601,13 @@ int ag_rollout_actions(ag_ctx* c, void* stream, const ag_rollout_params* p, cons
 int ag_rollout_work(ag_ctx* c, void* stream, const ag_rollout_params* p, const float* d_state0, const float* d_action,
                     float push_length, const float* h_tool_offsets, int32_t max_repeat, const float* d_phys_vec, int32_t* h_work) {
     if (!c) return AG_ERR_INVALID;
-    if (!d_action || !h_work) return fail(c, AG_ERR_INVALID, "ag_rollout_work: null pointer");
+    if (!p || !d_action || !h_work) return fail(c, AG_ERR_INVALID, "ag_rollout_work: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(c, hipSetDevice(c->device));
     CallSlot* sl = nullptr;
     int rc = slot_acquire(c, st, false, &sl);
     if (rc) return rc;
+    SlotGuard slot_guard(sl, st, false);
     const size_t nrep = (size_t)p->B * p->H;
     // scratch for what the plan kernel writes besides the plan: decoded actions (B,H,4) and the two flag words
     if (sl->work_cap < nrep * 4 + 64) {
@@ -1620,6 +1632,7 @@ int ag_rollout(ag_ctx* c, void* stream, const ag_rollout_params* p, const float*
     CallSlot* sl = nullptr;
     int rc = slot_acquire(c, st, false, &sl);                 // (the call below finds the same slot: same stream)
     if (rc) return rc;
+    SlotGuard slot_guard(sl, st, false);
     int* d_word = sl->d_words;
     HIPCHK(c, hipMemsetAsync(d_word, 0, 4, st));
     rc = ag_rollout_async(c, stream, p, d_state0, d_obj_mask, d_eef_xz, d_eef_delta, h_repeat, d_phys_vec, d_state_seqs, d_word);

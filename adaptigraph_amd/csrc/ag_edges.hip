@@ -511,17 +511,31 @@ __global__ __launch_bounds__(EW) void k_edge_count(EdgeDev a) {
             else block_topk<20>(a, l, b, rb, r1, thr, thr2);
         }
     }
-    for (int i = wave; i < a.N; i += EWAVES) {
-        const bool mine = i >= r0 && i < r1;
-        const bool is_tool = l.fl[i] & 2;
-        if (!mine && !(a.cta == 1 && is_tool)) continue;   // wave-uniform
-        if (blocks && !is_tool) continue;                  // done above
+    // r06: the rows of the slice directly, then the tool rows outside it found 64 flags at a time (the r01 loop walked ALL N rows
+    // per wavefront to find them: 127 dependent LDS reads per wave on a cloth-sized graph, whatever the slice held)
+    auto one_row = [&](int i, bool mine, bool is_tool) {
         int raw = 0, n;
         if (a.topk_active) n = row_topk(a, l, i, thr, thr2, a.ell + (long)b * a.ell_bstride + (long)i * a.ell_stride, &raw);
         else n = row_radius_count(a, l, i, thr, thr2, 0, &raw);
         if (lane == 0) {
             if (mine) a.deg[(long)b * a.N + i] = n;        // senders not governed by the tool rule
             if (a.cta == 1 && is_tool && raw) atomicOr(&l.misc[0], 1);
+        }
+    };
+    for (int i = r0 + wave; i < r1; i += EWAVES) {
+        const bool is_tool = l.fl[i] & 2;                  // wave-uniform
+        if (blocks && !is_tool) continue;                  // done above
+        one_row(i, true, is_tool);
+    }
+    if (a.cta == 1 && ntool) {                             // every tool row decides the batch flag (graph.py:277), in every slice
+        for (int c = wave; c < (a.N + 63) >> 6; c += EWAVES) {
+            const int j = 64 * c + lane;
+            unsigned long long tm = __ballot(j < a.N && (l.fl[j < a.N ? j : 0] & 2) && !(j >= r0 && j < r1));
+            while (tm) {
+                const int i = 64 * c + __ffsll((long long)tm) - 1;
+                tm &= tm - 1;
+                one_row(i, false, true);
+            }
         }
     }
     __syncthreads();
@@ -688,10 +702,19 @@ __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
 // ---- rollout fast path: index the slot-indexed graph left by k_edge_count (see EdgeArgs::ell_full).  One workgroup
 // per candidate: max_nR rule, receiver of every slot, list of the slots that are not self-loops (only those go
 // through the relation encoder), edge counts.  Integer scan, slot order = (receiver, position in row) = CSR order.
+// r06: slot-parallel.  The r02 version gave every thread whole rows and walked their slots one load at a time (deg -> ell -> ...:
+// a chain of ~12 dependent cache-miss latencies, 23 us whether the launch held one graph or 128).  Now pass 1 takes the slots
+// e = tid, tid + 1024, ... - consecutive lanes on consecutive slots, every load independent of every other - and leaves one
+// "goes through the relation encoder" bit per slot in LDS (a wave ballot: 64 consecutive slots = one 64-bit word, no atomics);
+// pass 2 gives every thread a contiguous run of those words: popcount, one block scan, and the set bits leave in slot order.
+// Same outputs bit for bit (recv per slot, ns list in slot order, pk, n_ns, n_edges, the share counters).
+constexpr int ELL_BITMAP_MAX_WORDS64 = 7168;               // 56 KB of dynamic LDS: 458,752 slots (N = 4096 rows of 112 slots)
 __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
-    __shared__ int scan[EW];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(smem);
+    __shared__ int wave_tot[EWAVES];
     __shared__ int n_shared;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (a.live && b >= *a.live) {                           // no forward left: nothing for the relation encoder to do
         if (tid == 0) { a.n_ns[b] = 0; a.n_edges[b] = 0; }
         return;
@@ -711,58 +734,73 @@ __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
     int* pk = a.send_pk ? a.send_pk + (long)b * a.edge_cap : nullptr;
     // (prefix sharing: a slot that starts from a later base state is not at the start state's forward - it shares nothing)
     const bool eligible = !a.share_start || a.share_start[a.share_cand ? a.share_cand[b] : a.share_b0 + b] == 0;
-    const int per = (a.N + EW - 1) / EW;
-    const int i0 = min(a.N, tid * per), i1 = min(a.N, i0 + per);
-    int mine = 0, shared = 0;
-    for (int i = i0; i < i1; ++i) {
-        if (hide) deg[i] = 0;
-        const int d = deg[i];
-        const int bd = (pk && i < a.share_No) ? a.base_deg[i] : 0;
-        const int* brow = a.base_send + (long)i * a.base_stride;
-        for (int t = 0; t < d; ++t) {
-            const int e = i * a.ell_stride + t;
-            const int j = ell[e];
-            int own = j != i ? 1 : 0;
-            if (pk) {
-                int v = j;
-                if (own && eligible && j < a.share_No)
-                    for (int u = 0; u < bd; ++u)
-                        if (brow[u] == j) { v = j | ((u + 1) << 12); own = 0; ++shared; break; }
-                pk[e] = v;
+    const int stride = a.ell_stride;
+    const int nslots = a.N * stride;
+    const int nw = (nslots + 63) >> 6;                      // 64-slot words
+    // ---- pass 1: one slot per lane
+    int shared = 0;
+    for (int e0 = wave * 64; e0 < nw * 64; e0 += EW) {      // wave-uniform trip count: the ballot below sees whole words
+        const int e = e0 + lane;
+        const bool in = e < nslots;
+        const int i = in ? e / stride : 0;
+        const int t = e - i * stride;
+        const int d = (in && !hide) ? deg[i] : 0;
+        const int j = in ? ell[e] : 0;                      // (allocated whatever the degree is: slot-indexed rows)
+        const bool valid = in && t < d;
+        bool own = valid && j != i;
+        if (pk && valid) {
+            int v = j;
+            if (own && eligible && i < a.share_No && j < a.share_No) {
+                const int bd = a.base_deg[i];
+                const int* brow = a.base_send + (long)i * a.base_stride;
+                for (int u = 0; u < bd; ++u)
+                    if (brow[u] == j) { v = j | ((u + 1) << 12); own = false; ++shared; break; }
             }
-            mine += own;
+            pk[e] = v;
         }
+        if (valid) recv[e] = i;
+        const unsigned long long bal = __ballot(own);
+        if (lane == 0) bits[e0 >> 6] = bal;
     }
-    scan[tid] = mine;
+    if (hide) for (int i = tid; i < a.N; i += EW) deg[i] = 0;
     __syncthreads();
-    for (int off = 1; off < EW; off <<= 1) {
-        int v = 0;
-        if (tid >= off) v = scan[tid - off];
-        __syncthreads();
-        scan[tid] += v;
-        __syncthreads();
+    // ---- pass 2: contiguous words per thread, block scan of the popcounts, set bits out in slot order
+    const int per = (nw + EW - 1) / EW;
+    const int w0 = min(nw, tid * per), w1 = min(nw, w0 + per);
+    int mine = 0;
+    for (int w = w0; w < w1; ++w) mine += __popcll(bits[w]);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
     }
-    int pos = scan[tid] - mine;
-    for (int i = i0; i < i1; ++i) {
-        const int d = deg[i];
-        for (int t = 0; t < d; ++t) {
-            const int e = i * a.ell_stride + t;
-            recv[e] = i;
-            const bool own = pk ? (ell[e] != i && (pk[e] >> 12) == 0) : ell[e] != i;   // pk[e]: written above by this thread
-            if (own) ns[pos++] = e;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < EWAVES; ++w) { const int v = wave_tot[w]; before += w < wave ? v : 0; all += v; }
+    int pos = before + incl - mine;
+    for (int w = w0; w < w1; ++w) {
+        unsigned long long m = bits[w];
+        while (m) {
+            ns[pos++] = (w << 6) + __ffsll((long long)m) - 1;
+            m &= m - 1;
         }
     }
     if (pk && a.share_stats) {
-        if (shared) atomicAdd(&n_shared, shared);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) shared += __shfl_xor(shared, o);
+        if (lane == 0 && shared) atomicAdd(&n_shared, shared);
         __syncthreads();
     }
     if (tid == EW - 1) {
-        a.n_ns[b] = scan[EW - 1];
+        a.n_ns[b] = all;
         a.n_edges[b] = hide ? 0 : total;
         if (a.overflow && total > a.max_nR) atomicMax(a.overflow, total);
         if (pk && a.share_stats) {                           // integer counters: order-free
             atomicAdd(a.share_stats + 0, (unsigned long long)n_shared);
-            atomicAdd(a.share_stats + 1, (unsigned long long)scan[EW - 1]);
+            atomicAdd(a.share_stats + 1, (unsigned long long)all);
         }
     }
 }
@@ -802,7 +840,11 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
     hipLaunchKernelGGL(k_edge_count, dim3(h.B * h.slices), dim3(EW), lds, st, a);
     if (mark) mark(mark_ctx, FAM_EDGE_COUNT, 1);
     if (mark) mark(mark_ctx, FAM_EDGE_EMIT, 0);
-    if (a.ell_full) hipLaunchKernelGGL(k_ell_index, dim3(h.B), dim3(EW), 0, st, a);
+    if (a.ell_full) {
+        const long nw = ((long)h.N * a.ell_stride + 63) >> 6;
+        if (nw > ELL_BITMAP_MAX_WORDS64) return hipErrorInvalidValue;     // (N <= 4096 and topk + M <= 112: never on this path)
+        hipLaunchKernelGGL(k_ell_index, dim3(h.B), dim3(EW), (size_t)nw * 8, st, a);
+    }
     else hipLaunchKernelGGL(k_edge_emit, dim3(h.B * h.slices), dim3(EW), lds, st, a);
     if (mark) mark(mark_ctx, FAM_EDGE_EMIT, 1);
     return hipGetLastError();

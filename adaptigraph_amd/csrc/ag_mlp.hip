@@ -834,8 +834,13 @@ __device__ __forceinline__ void mma_b3(const float* wl, const bf16x8* bh, const 
 // share a CU and cover each other's prologue and barrier waits.  (Measured alternatives: register staging per half
 // unit - prefetch window too short, waves parked 24 %; 8-wave workgroups with a 4-slot ring - no faster, every
 // prologue exposed.)
+#ifdef AG_B3_WG512   // A/B experiment (r06, correct results): ONE 8-wavefront workgroup per CU, its eight waves share one weight ring
+constexpr int WGB = 512, WGB_ROWS = 256, WGB_PER_CU = 1;
+#else
 constexpr int WGB = 256;                    // 4 wavefronts; two workgroups per CU cover each other's prologue / barriers
 constexpr int WGB_ROWS = 128;
+constexpr int WGB_PER_CU = 2;
+#endif
 constexpr int NSLOT = 2;                    // LDS ring slots of one unit each (2 x 30,720 B per workgroup)
 constexpr int UNIT_FLOATS = PH_FLOATS;
 
@@ -926,7 +931,7 @@ __device__ __forceinline__ void first_b3(const float* wl, const float* f, f32x16
     }
 }
 
-__global__ __launch_bounds__(WGB, 2) void k_edge_enc_b3(GDev g) {
+__global__ __launch_bounds__(WGB, WGB_PER_CU) void k_edge_enc_b3(GDev g) {
     __shared__ __attribute__((aligned(16))) float lds[NSLOT * UNIT_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = (int)(blockIdx.x % (unsigned)g.B);
@@ -973,7 +978,7 @@ __global__ __launch_bounds__(WGB, 2) void k_edge_enc_b3(GDev g) {
     store_rows(x, g.C, (long)b * g.c_cap + el, lane, valid);
 }
 
-__global__ __launch_bounds__(WGB, 2) void k_node_enc_b3(GDev g) {
+__global__ __launch_bounds__(WGB, WGB_PER_CU) void k_node_enc_b3(GDev g) {
     __shared__ __attribute__((aligned(16))) float lds[NSLOT * UNIT_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long rend = g.row0 + g.nrows;
@@ -1011,7 +1016,7 @@ __global__ __launch_bounds__(WGB, 2) void k_node_enc_b3(GDev g) {
 }
 
 template <bool LAST, bool SHARE>
-__global__ __launch_bounds__(WGB, 2) void k_node_prop_b3(GDev g) {
+__global__ __launch_bounds__(WGB, WGB_PER_CU) void k_node_prop_b3(GDev g) {
     __shared__ __attribute__((aligned(16))) float lds[NSLOT * UNIT_FLOATS];
     constexpr int KIND = LAST ? 3 : 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1120,7 +1125,7 @@ hipError_t launch_edge_enc(const float* w, const GraphBufs& g, hipStream_t st) {
     d.dbg = diag_edge_begin(g.diag, nwg, st);
     probing = d.dbg != nullptr;
 #endif
-    if (d.wb3) hipLaunchKernelGGL(k_edge_enc_b3, dim3((unsigned)(rows / WGB_ROWS)), dim3(WGB), 0, st, d);
+    if (d.wb3) hipLaunchKernelGGL(k_edge_enc_b3, dim3((unsigned)g.B * (unsigned)((g.c_cap + WGB_ROWS - 1) / WGB_ROWS)), dim3(WGB), 0, st, d);
     else if (g.n_his == 5) hipLaunchKernelGGL(k_edge_enc<5>, dim3(nwg), dim3(WG), 0, st, d);
     else {
         unsigned grid = nwg;

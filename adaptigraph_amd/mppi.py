@@ -50,6 +50,19 @@ def angle_normalize(x):
     return clip_actions(a, -inf, inf)[..., 2]
 
 
+_BETA = {}
+
+
+def _beta(H, dev):
+    """plan_utils.py:62 `beta = 0.1 * (10 ** i)` per look-ahead step, resident on the device: a constant, uploaded once.  (Built per
+    call it is a pageable host-to-device copy, which blocks the host until everything queued on the stream has run - once per update
+    iteration of a planner call, random_interact.py's configuration: 4 x ~10 ms of host time per call in the r06 trace.)"""
+    key = (H, dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _BETA:
+        _BETA[key] = torch.tensor([0.1 * (10 ** i) for i in range(H)], dtype=torch.float32).to(dev)
+    return _BETA[key]
+
+
 def sample_action_seq(act_seq, action_lower_lim, action_upper_lim, n_sample, device, iter_index=0, noise_level=0.3,
                       push_length=0.10, _draws=None):
     """plan_utils.py:42-77 -> (n_sample, n_look_ahead, 4).  iter_index 0: uniform resampling inside the limits; else
@@ -72,7 +85,7 @@ def sample_action_seq(act_seq, action_lower_lim, action_upper_lim, n_sample, dev
     else:
         noise = _dev_f32(_draws, dev)
     assert noise.shape == (H, n_sample, 4)
-    scale = torch.tensor([0.1 * (10 ** i) for i in range(H)], dtype=torch.float32).to(dev)          # :62
+    scale = _beta(H, dev)                                                                           # :62
     nominal = _dev_f32(act_seq, dev)
     eng.check(eng.lib.ag_mppi_sample(eng.ctx, current_stream(dev), ptr(nominal), ptr(lo), ptr(hi), ptr(noise), ptr(scale),
                                      n_sample, H, 1, float(push_length), ptr(out)))

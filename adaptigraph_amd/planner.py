@@ -202,6 +202,7 @@ class Planner(object):
         self._pipe_i = 0
         self._call_flags = None      # flag tensors of the rollouts of the call being enqueued
         self._call_one_stream = True # the call being enqueued keeps the engine on its one stream (dealt calls)
+        self._dealt_prefix_later = False   # True: dealt calls keep the contact-free prefix in update rounds >= 1 too (A/B switch, _rollout)
         self._bound_ok = None        # (_repeats_within_bound's verdict,) once decided
         self._pending = []           # (pinned flag copy, done event) of calls whose flags have not been looked at
         self._series_i = 0           # calls since the last merge_res = index of the next call in the caller's chunk loop
@@ -376,12 +377,23 @@ class Planner(object):
         task = self._eng_rollout.keywords["ppm_optimizer"].task_config
         return int(task["max_nR"]), _repeat_bound(task)
 
-    def _rollout(self, state_cur, act_seqs):
+    def _rollout(self, state_cur, act_seqs, update_round=0):
         """model_rollout_fn; inside a pipelined call the engine's dynamics() is told not to wait for its flags"""
         if self._call_flags is None:
             return self.model_rollout(state_cur, act_seqs)
         flags = torch.zeros(2, dtype=torch.int32, device=state_cur.device)
         self._call_flags.append(flags)
+        if update_round > 0 and self._call_one_stream and not self._dealt_prefix_later:
+            # A dealt call's LATER update rounds (n_update_iter > 1, random_interact.py:172) run without the contact-free prefix:
+            # prefix sharing plans its launches on the host from a census of the batch, i.e. the call waits for that census - and
+            # round i + 1's samples come out of round i's rewards, so the wait is for the whole of round i and the next dealt call
+            # cannot be enqueued before this one has all but finished on the GPU.  Without it the device-planned rollout needs no
+            # answer from the GPU.  Round 0 keeps it: uniform samples over the action box mostly never touch (its census sits at
+            # the head of the side stream), later rounds sample around the best push so far.  Same results either way, bit for bit.
+            kw = self._eng_rollout.keywords
+            eng = kw["model"].engine(torch.device(kw["device"]))
+            with eng.options(streams=1, share_prefix=0):
+                return self._eng_rollout(state_cur, act_seqs, _sync=False, _overflow_flag=flags)
         # a dealt call stays on its one stream (option streams = 1 for the duration of the enqueue): six of them already run side
         # by side, and a fork inside each doubles the launches and lets in-library streams share hardware queues with the side
         # streams (rope planner call 168 +- 10 ms with the engine's by-size fork, 147 without, run after run)
@@ -536,7 +548,7 @@ class Planner(object):
             act_seqs = self.sample_action_sequences(act_seq, iter_index=i)
             assert type(act_seqs) == torch.Tensor
             assert act_seqs.shape == (self.n_sample, self.n_look_ahead, self.action_dim)
-            model_out = self._rollout(state_cur, act_seqs)
+            model_out = self._rollout(state_cur, act_seqs, update_round=i)
             assert type(model_out["state_seqs"]) == torch.Tensor
             eval_out = self._evaluate(model_out, act_seqs, state_cur)
             reward_seqs = eval_out["reward_seqs"]

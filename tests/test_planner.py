@@ -311,3 +311,72 @@ def test_the_references_chunk_loop_is_dealt_to_the_ranks_and_merges_to_the_one_r
         for key in ("golden", "placeholders_are_nan", "equal_one_rank", "generator_in_step", "second_series", "error_everywhere",
                     "usable_after_error", "refused"):
             assert o[key] is True, (r, key, o)
+
+
+# ------------------------------------------------------------------------------- r06: when calls are dealt, and saying when not
+def _engine_planner(upper_len=10.0, task_upper=10.0, **over):
+    """a Planner configured like plan.py:177-207 around the ENGINE's dynamics() - constructed only, nothing runs (no GPU here)"""
+    import types
+    from functools import partial
+    import adaptigraph_amd as ag
+    mc = dict(verbose=False, nf_particle=150, nf_relation=150, nf_effect=150, nf_physics=10, attr_dim=2, state_dim=0, offset_dim=0,
+              action_dim=3, density_dim=0, pstep=3, sequence_len=4, rel_particle_dim=0, rel_attr_dim=2, rel_group_dim=1,
+              rel_distance_dim=3, rel_density_dim=0)
+    m = ag.DynamicsPredictor(mc, {"material_index": {"rope": 0}, "rope": {"physics_params": [{"name": "p", "use": True}]}},
+                             {"n_his": 4, "materials": ["rope"]}, "cuda:0")
+    task = dict(adj_thresh=0.5, topk=10, connect_tools_all=False, sim_real_ratio=10, push_length=0.1, gripper_enable=False, max_n=1,
+                max_nR=4000, n_his=4, eef_num=1, material="rope", pusher_points=[[0.0, 0.0, 0.12]], material_dims={"rope": 1},
+                material_indices={"rope": 0})
+    if task_upper is not None:
+        task["action_upper_lim"] = [0.0, 4.5, 3.14, task_upper]
+    ppm = types.SimpleNamespace(task_config=task, eef_num=1, material="rope", material_dims=task["material_dims"],
+                                material_indices=task["material_indices"], physics_param={"rope": torch.tensor([0.5])}, adj_thresh=0.5)
+    lo, hi = torch.tensor([-4.5, -2.5, -3.14, 2.0]), torch.tensor([0.0, 4.5, 3.14, upper_len])
+    cfg = {"action_dim": 4, "model_rollout_fn": partial(ag.dynamics, model=m, device="cuda:0", ppm_optimizer=ppm),
+           "evaluate_traj_fn": toy_cost, "n_sample": 8, "n_look_ahead": 1, "n_update_iter": 1, "reward_weight": 1.0,
+           "sampling_action_seq_fn": partial(ag.sample_action_seq, action_lower_lim=lo, action_upper_lim=hi, n_sample=8, device="cuda:0"),
+           "optimize_action_mppi_fn": partial(ag.optimize_action_mppi, action_lower_lim=lo, action_upper_lim=hi),
+           "clip_action_seq_fn": partial(ag.clip_actions, action_lower_lim=lo, action_upper_lim=hi),
+           "action_lower_lim": lo, "action_upper_lim": hi, "planner_type": "MPPI", "device": "cuda:0", "rollout_best": True}
+    cfg.update(over)
+    return Planner(cfg)
+
+
+def test_dealing_needs_repeats_that_cannot_leave_the_task_configs_bound():
+    """A call that does not wait for its rollout cannot fall back to the host decode for a push longer than the task config
+    allows (forward_dynamics.py:156 accepts any length): calls are dealt only when the limits the sampler, the MPPI update and
+    the clamp work with keep int(length) within task_config['action_upper_lim'][3]."""
+    assert _engine_planner()._repeats_within_bound() is None
+    assert _engine_planner(upper_len=10.9)._repeats_within_bound() is None          # int(10.9) = 10 <= 10
+    why = _engine_planner(upper_len=12.0)._repeats_within_bound()
+    assert why is not None and "12.0" in why and "10" in why
+    assert "action_upper_lim" in _engine_planner(task_upper=None)._repeats_within_bound()
+    own = _engine_planner(sampling_action_seq_fn=lambda a, iter_index=None: a[None].repeat(8, 1, 1))
+    assert "sampling_action_seq_fn" in own._repeats_within_bound()
+    # the planner's own defaults clamp to its own limits
+    d = _engine_planner()
+    d.sample_action_sequences, d.optimize_action_mppi, d.clip_action_sequences = (d.sample_action_sequences_default,
+                                                                                  d.optimize_action_mppi_default, d.clip_actions_default)
+    d._bound_ok = None
+    assert d._repeats_within_bound() is None
+
+
+def test_planner_says_once_why_calls_are_not_dealt(caplog):
+    import logging
+    import adaptigraph_amd as ag
+    with caplog.at_level(logging.WARNING, logger="adaptigraph_amd.planner"):
+        pl = _engine_planner()
+        assert pl.pipeline_chunks == 6 and pl._pipeline_off_static() is None and not caplog.records      # nothing to say
+        inner = pl.model_rollout
+        _engine_planner(model_rollout_fn=lambda s, a: inner(s, a))                                         # a lambda around dynamics()
+        assert len(caplog.records) == 1 and "functools.partial(adaptigraph_amd.dynamics" in caplog.records[0].getMessage()
+        _engine_planner(verbose=True)
+        _engine_planner(pipeline_chunks=0)
+        msgs = [r.getMessage() for r in caplog.records]
+        assert len(msgs) == 3 and "verbose" in msgs[1] and "pipeline_chunks" in msgs[2]
+        assert all(m.startswith("planner: calls are not dealt to side streams") for m in msgs)
+    # a planner on CPU stand-ins (the tests above) is not told anything
+    with caplog.at_level(logging.WARNING, logger="adaptigraph_amd.planner"):
+        caplog.clear()
+        _planner()
+        assert not caplog.records

@@ -52,8 +52,8 @@ def main():
             torch.manual_seed(0)
             act_seq = torch.rand((1, 4), device=dev) * (hi - lo) + lo
             out = {}
-            for label, pipe, reuse in (("strict", 0, False), ("default", 6, True)):
-                planner.pipeline_chunks, planner.reuse_best_rollout = pipe, reuse
+            for label, pipe, reuse, later in (("strict", 0, False, False), ("default", 6, True, False), ("prefix_later", 6, True, True)):
+                planner.pipeline_chunks, planner.reuse_best_rollout, planner._dealt_prefix_later = pipe, reuse, later
                 for _ in range(2):
                     torch.manual_seed(1); BP.loop_call(planner, s0, act_seq, n_chunk)
                 torch.cuda.synchronize()
@@ -68,7 +68,8 @@ def main():
             print(json.dumps({"config": f"{mat} {cloud.shape[0]}+{task['eef_num']} particles, random_interact.py planner call: n_update_iter 5, "
                                         f"n_sample 1000 as {n_chunk} chunk(s) of {S}, n_look_ahead 1",
                               "ms_per_planner_call_strict": out["strict"][0], "ms_per_planner_call_default": out["default"][0],
-                              "bit_equal": out["strict"][1] == out["default"][1], "best_reward": out["default"][2],
+                              "ms_per_planner_call_dealt_with_prefix_in_later_rounds": out["prefix_later"][0],
+                              "bit_equal": out["strict"][1] == out["default"][1] == out["prefix_later"][1], "best_reward": out["default"][2],
                               "default_is": "one call, one wait at its end" if n_chunk == 1 else "two calls dealt to side streams, waited for in merge_res"}),
                   flush=True)
 
