@@ -14,9 +14,15 @@ arithmetic of the hot path.  What is new:
   winners are compared by a batch-of-one re-evaluation - so the chunked entry evaluates chunk by chunk and merges
   exactly like the loop.  Per-candidate rollouts do not depend on what else is in the batch, hence the
   result equals the loop's bit for bit (tests/test_gpu_more.py).
-* `group` (config key, optional): the chunks are dealt to the ranks of a torch.distributed group; every rank draws all
-  samples (same seed), rolls out and evaluates its chunks, the chunk winners (n_chunk x n_look_ahead x action_dim
-  floats) are all-gathered, and every rank re-evaluates the winners itself - no batch-global reduction crosses ranks.
+* `group` (config key, optional; r06): with a torch.distributed group and an announced loop (`planner.total_chunks = n_chunk`, what
+  plan.py:210 and random_interact.py:188 do) the reference's UNCHANGED loop is dealt to the ranks: call ci of the series is evaluated
+  by rank ci % world (on that rank's side streams), every other rank only draws the call's samples - so all generators stay in
+  step - and gets a placeholder result (NaN `act_seq`, no outputs); `merge_res` all-gathers (error code, winner's score, winner's
+  action sequence) per call - n_chunk x (2 + n_look_ahead x action_dim) numbers -, takes the reference's argmax on every rank and
+  broadcasts the winning call's `best_model_output` / `best_eval_output` from its owner.  40 chunks on 8 ranks: 5 calls per rank.
+  The two callables must be rank-local (no collective of their own: the ranks evaluate different calls); an error any rank meets
+  ("Exceeds max dims", ...) is raised by `merge_res` on EVERY rank, after the exchange - never inside one rank's call, which would
+  leave the others hanging in the collective.  `trajectory_optimization_chunked` deals contiguous chunk ranges the same way.
 * `planner_type` 'GD' raises NotImplementedError: it differentiates through the rollout and the engine has no backward.
 * The reference's own loop - 40 x `trajectory_optimization`, then `merge_res` - is served as it stands (r05): when
   `model_rollout_fn` is the engine's `dynamics` behind a `functools.partial` (what plan.py:190 builds), consecutive calls on
@@ -26,9 +32,18 @@ arithmetic of the hot path.  What is new:
   the call's end before the result is handed back - so results are used in stream order as always - and the next call starts on
   another stream while this one still runs.  Same samples (the generator advances on the host, in call order), same per-candidate
   results (a rollout does not depend on its batch, stream or neighbours, bit for bit), so the same winner.  What changes:
-  "Exceeds max dims" of call i surfaces at a later call or at `merge_res` - where the reference's loop first reads a result
-  back (planner.py:312-314) - instead of inside call i; `pipeline_chunks: 0` restores the strict behaviour.  Also (r05) the
-  winner's rollout is taken out of its batch (`reuse_best_rollout`) by default when the rollout is the engine's.
+  "Exceeds max dims" of call i surfaces at a later call, at the loop's last call or at `merge_res` - where the reference's loop
+  first reads a result back (planner.py:312-314) - instead of inside call i.  r06: this deferral is tied to the caller having
+  ANNOUNCED the loop (`planner.total_chunks = n_chunk > 1`, as both reference call sites do) or having put 'pipeline_chunks' into
+  the config: a planner that is called once per control step and never merged raises inside the call, as the reference does.
+  Dealing also needs push lengths that provably stay within the task config's bound (`_repeats_within_bound`: a call that does
+  not wait cannot fall back to the host decode), and the series' other GPU inputs (cost targets, ...) must not change between
+  its first call and `merge_res` (the side streams are ordered behind the caller's stream at the series' first call and whenever
+  `state_cur` / `act_seq` change).  When calls are NOT dealt the class says why, once (logger `adaptigraph_amd.planner`).
+  A call that is not dealt still waits only ONCE, at its end, for all its update rounds (`_one_wait_call`), and the best-so-far
+  selection between rounds (planner.py:254-260) stays on the device.  `pipeline_chunks: 0` restores the strict behaviour: every
+  rollout waits for its flags.  Also (r05) the winner's rollout is taken out of its batch (`reuse_best_rollout`) by default when
+  the rollout is the engine's.
 
 The progress lines the reference prints on every call go to stdout only with `verbose`.
 """

@@ -619,10 +619,10 @@ def main():
             return tj["hbm_bytes_per_launch"] if abs(tj[key] - want) <= 0.01 * want else None
 
         def latest(stem):                                   # the newest round's committed measurement of that name
-            for r in ("r05", "r04", "r03"):
+            for r in ("r06", "r05", "r04", "r03"):
                 if os.path.exists(os.path.join(ROOT, "profiles", f"{r}_{stem}")):
                     return f"{r}_{stem}"
-            return f"r05_{stem}"
+            return f"r06_{stem}"
         traffic_file = latest("traffic_k_edge_enc.json")
         traffic = pmc_traffic(traffic_file, "edges_per_launch", edges_per_launch)
         achieved = FLOP_PER_EDGE * edges_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0

@@ -3,7 +3,7 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUNDS = ("r05", "r04", "r03")                                       # bench.py takes the newest round's file of a name
+ROUNDS = ("r06", "r05", "r04", "r03")                                       # bench.py takes the newest round's file of a name
 
 
 def _latest(stem):

@@ -70,6 +70,33 @@ if ws:
     json.dump({"what": "tools/two_rank_planner_shards.py: 4000 pushes of the shipped rope sampler sharded by WORK (adaptigraph_amd.rollout_work) "
                        "and by count, one rank and two ranks on one GPU (gloo); reward hashes must agree", **ws},
               open(os.path.join(P, f"{rnd}_work_shards.json"), "w"), indent=1)
+# r06: the interact configuration, the rank-dealt planner loop, the bare two-rank launch, blocking-call traces
+def _last_json(path):
+    rows = [l for l in open(path) if l.startswith("{")] if os.path.exists(path) else []
+    return json.loads(rows[-1]) if rows else None
+
+
+if os.path.exists(os.path.join(F, "interact_configs.jsonl")) and os.path.getsize(os.path.join(F, "interact_configs.jsonl")):
+    shutil.copy(os.path.join(F, "interact_configs.jsonl"), os.path.join(P, f"{rnd}_interact_configs.jsonl"))
+ranks = {tag: _last_json(os.path.join(F, f"planner_loop_{tag}.json")) for tag in ("1rank", "2ranks")}
+if all(ranks.values()):
+    json.dump({"what": "tools/two_rank_planner_loop.py: the reference's UNCHANGED 40-call planner loop (plan.py:210, 241-247) on the shipped rope "
+                       "configuration with planner_config['group'], one rank and two ranks on ONE GPU (gloo): call ci on rank ci % world, "
+                       "merge_res all-gathers the winners; result and generator SHA-256 must not depend on the number of ranks (two ranks "
+                       "share the card here, so the time says nothing about scaling)", **ranks,
+               "result_bit_equal": ranks["1rank"]["result_sha256"] == ranks["2ranks"]["result_sha256"]},
+              open(os.path.join(P, f"{rnd}_planner_loop_ranks.json"), "w"), indent=1)
+bare = _last_json(os.path.join(F, "bench_bare_two_ranks.json"))
+if bare:
+    json.dump({"what": "AG_BENCH_SHARE_GPU=1 AG_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 ... with NO launcher in front, full "
+                       "size: the parent starts python -m torch.distributed.run itself (multi_gpu.launched_by); both ranks share the one GPU of "
+                       "the box, so ms_per_step is not a scaling figure", "line": {k: bare[k] for k in ("value", "n_gpus", "ms_per_step", "reward_sha256", "multi_gpu", "config")},
+               "one_rank_reward_sha256": plain["reward_sha256"], "reward_vectors_bit_equal": bare["reward_sha256"] == plain["reward_sha256"]},
+              open(os.path.join(P, f"{rnd}_bare_two_rank_launch.json"), "w"), indent=1)
+for m in ("interact1", "interact1_strict", "interact2", "interact2_strict"):
+    src_t = os.path.join(F, f"planner_trace_rope_{m}.json")
+    if os.path.exists(src_t) and os.path.getsize(src_t):
+        shutil.copy(src_t, os.path.join(P, f"{rnd}_planner_trace_rope_{m}.json"))
 # per-config evidence (tools/profile_configs.sh)
 shutil.copy(os.path.join(C, "other_configs.jsonl"), os.path.join(P, f"{rnd}_other_configs.jsonl"))
 for c in ("rope64", "granular", "mixed"):
