@@ -116,7 +116,8 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ void load_candidate(const EdgeDev& a, const EdgeLds& l, int b, bool want_pos) {
     const float* p = a.pos + (long)b * a.pos_bstride;
     if (threadIdx.x < 64) l.misc[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < a.N; i += EW) {
+#pragma unroll 2
+    for (int i = threadIdx.x; i < a.N; i += EW) {           // (two trips' loads in flight together: a cloth-sized graph takes two)
         if (want_pos) {
             l.x[i] = p[3 * i + 0];
             l.y[i] = p[3 * i + 1];
@@ -595,10 +596,20 @@ __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
     const int ntool = l.misc[2];
     const bool tools_on = a.cta && flag && ntool > 0;
     int base = 0, total = 0;
-    for (int s = 0; s < a.slices; ++s) {
-        const int v = a.slice_tot[b * a.slices + s];
-        if (s < sl) base += v;
-        total += v;
+    {   // (one load per thread + a reduction instead of a loop over the slices in every thread: see k_ell_index)
+        int pb = 0, pt = 0;
+        for (int s = threadIdx.x; s < a.slices; s += EW) {
+            const int v = a.slice_tot[b * a.slices + s];
+            pb += s < sl ? v : 0;
+            pt += v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { pb += __shfl_xor(pb, o); pt += __shfl_xor(pt, o); }
+        if (lane == 0) { l.scan[2 * wave] = pb; l.scan[2 * wave + 1] = pt; }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < EWAVES; ++w) { base += l.scan[2 * w]; total += l.scan[2 * w + 1]; }
+        __syncthreads();                                    // l.scan is the scan buffer below
     }
     // ---- exclusive scan of this slice's degrees: each thread owns a contiguous run of rows
     const int per = (nrows + EW - 1) / EW;
@@ -720,8 +731,20 @@ __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
         return;
     }
     if (tid == 0) n_shared = 0;
+    // edges of the candidate = sum of its slice totals: one load per thread and a reduction (a loop over the slices in every
+    // thread is a chain of dependent scalar loads - 127 of them for one cloth-sized graph: most of the kernel's 24 us)
     int total = 0;
-    for (int s = 0; s < a.slices; ++s) total += a.slice_tot[b * a.slices + s];
+    {
+        int part = 0;
+        for (int s = tid; s < a.slices; s += EW) part += a.slice_tot[b * a.slices + s];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) wave_tot[wave] = part;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < EWAVES; ++w) total += wave_tot[w];
+        __syncthreads();                                    // wave_tot is used again by the scan below
+    }
     const bool hide = total > a.max_nR && a.zero_on_overflow;   // downstream kernels then see an empty graph
     int* deg = a.deg + (long)b * a.N;
     const int* ell = a.ell + (long)b * a.ell_bstride;
@@ -739,13 +762,25 @@ __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
     const int nw = (nslots + 63) >> 6;                      // 64-slot words
     // ---- pass 1: one slot per lane
     int shared = 0;
-    for (int e0 = wave * 64; e0 < nw * 64; e0 += EW) {      // wave-uniform trip count: the ballot below sees whole words
+    constexpr int UN = 8;                                   // words per wavefront and trip: the loads of all eight are issued together
+    for (int eb = wave * 64; eb < nw * 64; eb += UN * EW) { // wave-uniform trip count: the ballots below see whole words
+      int iu[UN], du[UN], ju[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int e = eb + u * EW + lane;
+        const bool in = e < nslots;
+        iu[u] = in ? e / stride : 0;
+        du[u] = (in && !hide) ? deg[iu[u]] : 0;
+        ju[u] = in ? ell[e] : 0;                            // (allocated whatever the degree is: slot-indexed rows)
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int e0 = eb + u * EW;
+        if (e0 >= nw * 64) break;                           // wave-uniform
         const int e = e0 + lane;
         const bool in = e < nslots;
-        const int i = in ? e / stride : 0;
+        const int i = iu[u], d = du[u], j = ju[u];
         const int t = e - i * stride;
-        const int d = (in && !hide) ? deg[i] : 0;
-        const int j = in ? ell[e] : 0;                      // (allocated whatever the degree is: slot-indexed rows)
         const bool valid = in && t < d;
         bool own = valid && j != i;
         if (pk && valid) {
@@ -761,6 +796,7 @@ __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
         if (valid) recv[e] = i;
         const unsigned long long bal = __ballot(own);
         if (lane == 0) bits[e0 >> 6] = bal;
+      }
     }
     if (hide) for (int i = tid; i < a.N; i += EW) deg[i] = 0;
     __syncthreads();

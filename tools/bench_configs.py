@@ -252,7 +252,8 @@ def ppm_sweep(n_points=50, n_inter=20, reps=3):
     return out
 
 
-CONFIGS = {"rope1": lambda: homogeneous("rope", 1, 1, 10, 20), "rope64": lambda: homogeneous("rope", 64, 2, 10, 10),
+CONFIGS = {"rope1": lambda: homogeneous("rope", 1, 1, 10, 20), "cloth1": lambda: homogeneous("cloth", 1, 2, 10, 20),
+           "rope64": lambda: homogeneous("rope", 64, 2, 10, 10),
            "granular": lambda: homogeneous("granular", 256, 2, 10, 3), "mixed": lambda: mixed(512, 20, 3), "ppm": ppm_sweep}
 
 if __name__ == "__main__":
