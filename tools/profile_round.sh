@@ -56,22 +56,6 @@ AG_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --gpus 1 --steps 5 --war
 timeout -k 10 300 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-bf16x3 --no-mpc-iter --no-kernel-profile > $O/bench_plain_short.json 2> $O/bench_plain_short.err
 timeout -k 10 120 python tools/trace_mpc_iter.py > $O/small_call_latency.json 2> /dev/null
 cd $R
-# ---- r06
-# random_interact.py's planner configuration (n_update_iter 5, n_sample 1000 as 1 / 2 chunks), strict vs default
-timeout -k 10 300 python tools/bench_interact.py > $O/interact_configs.jsonl 2> $O/interact_configs.err || true
-# the reference's unchanged 40-call loop with planner_config['group']: one rank, then two ranks on this one GPU (gloo)
-AG_LOOP_CHUNKS=40 timeout -k 10 300 python tools/two_rank_planner_loop.py > $O/planner_loop_1rank.json 2> $O/planner_loop_ranks.err || true
-AG_LOOP_CHUNKS=40 AG_BENCH_SHARE_GPU=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 tools/two_rank_planner_loop.py > $O/planner_loop_2ranks.json 2>> $O/planner_loop_ranks.err || true
-# `python bench.py --gpus 2` with NO launcher in front, full size: the parent starts its own two ranks (rehearsal: both on this GPU, gloo)
-AG_BENCH_SHARE_GPU=1 AG_BENCH_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 2 --steps 5 --warmup 2 --no-bf16x3 --no-mpc-iter --no-kernel-profile > $O/bench_bare_two_ranks.json 2> $O/bench_bare_two_ranks.err || true
-# HIP-API + kernel traces of the interact configuration (blocking HIP calls per planner call), rope
-export TMPDIR=/tmp
-cd /tmp
-for m in interact1 interact1_strict interact2 interact2_strict; do
-  AG_TRACE_META_DIR=$O/tr_rope_$m timeout -k 10 200 rocprofv3 --hip-trace --kernel-trace --output-format csv -d $O/tr_rope_$m -o t -- python3 $R/tools/trace_planner_loop.py run rope $m > $O/tr_rope_$m.log 2>&1 || true
-  python3 $R/tools/trace_planner_loop.py report $O/tr_rope_$m > $O/planner_trace_rope_$m.json || true
-done
-cd $R
 # (SKIP_CONFIGS=1: the per-config evidence is then run as a call of its own - gpurun -- 'bash tools/profile_configs.sh' - the two
 # together can exceed one call's time limit)
 [ "${SKIP_CONFIGS:-0}" = 1 ] || bash tools/profile_configs.sh > $O/profile_configs.log 2>&1 || tail -20 $O/profile_configs.log
