@@ -38,6 +38,14 @@ def test_bench_default_profile_is_a_bench_line():
         v = d["parity_check"]["vs_reference"]
         assert v["n_candidates"] >= 60 and v["ok"] and all(f["near_tie_in_the_reference"] for f in v["flips_vs_reference"])
         assert all(f["checker_induced"] is not None for f in d["parity_check"]["edge_flips"])
+        if "ok_clause" in v:                                     # r06: the line says which clause held, flips carry their reach
+            assert v["ok_clause"].startswith(("every covered candidate within tol", f"{v['candidates_within_tol_all_steps']} of {v['n_candidates']} within tol"))
+            first = {}
+            for f in v["flips_vs_reference"]:                    # a candidate's FIRST step out of tolerance is the attributed one
+                if f["candidate"] not in first or f["lookahead_step"] < first[f["candidate"]]["lookahead_step"]:
+                    first[f["candidate"]] = f
+            assert all(f["reference_selection_margin"] < f["margin_within_reach_of_the_deviation_before"] for f in first.values())
+            assert d["env"]["hw_queues"]["GPU_MAX_HW_QUEUES"] == d["env"]["GPU_MAX_HW_QUEUES"]
     # the names bench.py looks up must be the files that are committed
     src = open(os.path.join(ROOT, "bench.py")).read()
     for stem in ("traffic_k_edge_enc.json", "traffic_k_node_prop.json"):
