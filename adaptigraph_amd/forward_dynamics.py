@@ -243,7 +243,7 @@ def dynamics_masked(state_init, state_mask, action, model, device, ppm_optimizer
 
 
 @torch.no_grad()
-def dynamics_mixed(batches, device, one_stream_each=None):
+def dynamics_mixed(batches, device, one_stream_each=None, largest_first=True, streams_each=None):
     """One evaluation of a MIXED batch of variable-size graphs (BASELINE configs[4]: rope + granular + cloth candidates, every one
     with its own particle count, graph rebuilt every step): `batches` is a list of per-material argument tuples
         (state_init (B_m,max_nobj_m,3), state_mask (B_m,max_nobj_m), action (B_m,4), model_m, ppm_optimizer_m[, physics_param_m])
@@ -255,7 +255,10 @@ def dynamics_mixed(batches, device, one_stream_each=None):
     under the large graphs' kernels; the caller's stream waits (on the GPU) for all of them, and ONE read-back brings every
     batch's flags: Exception("Exceeds max dims") (utils.py:63-65) if any graph of any batch outgrew its max_nR.  Pass CPU-resident
     actions / physics parameters to keep the call free of other read-backs.
-    one_stream_each: keep every engine on its one side stream instead of letting it fork large batches onto its in-library streams."""
+    one_stream_each: keep every engine on its one side stream instead of letting it fork large batches onto its in-library streams
+    (streams_each: that many in-library streams per engine instead of its by-size choice).  largest_first: enqueue the batches in
+    descending order of their padded row count, so that the small graphs' launch chains fill the large ones' gaps instead of forming
+    the tail (results come back in the order of `batches` either way)."""
     from .context import side_streams
     dev = _require_gpu(device)
     n = len(batches)
@@ -267,14 +270,16 @@ def dynamics_mixed(batches, device, one_stream_each=None):
     entry.record(cur)
     side = side_streams(dev, n)
     pin = bool(one_stream_each)                             # (measured on configs[4]: 167.9 ms with the engines forking by size, 170.9 pinned)
-    out = []
-    for m, (batch, st) in enumerate(zip(batches, side)):
+    out = [None] * n
+    order = sorted(range(n), key=lambda m: -int(batches[m][0].shape[0]) * int(batches[m][0].shape[1])) if largest_first else list(range(n))
+    for m in order:
+        batch, st = batches[m], side[m]
         state_init, state_mask, action, model, ppm = batch[:5]
         phys = batch[5] if len(batch) > 5 else None
         st.wait_event(entry)
         with torch.cuda.stream(st):
-            if pin and isinstance(model, DynamicsPredictor):
-                with model.engine(dev).options(streams=1):
+            if (pin or streams_each) and isinstance(model, DynamicsPredictor):
+                with model.engine(dev).options(streams=1 if pin else int(streams_each)):
                     res = dynamics_masked(state_init, state_mask, action, model, dev, ppm, physics_param=phys, _sync=False, _overflow_flag=flags[m])
             else:
                 res = dynamics_masked(state_init, state_mask, action, model, dev, ppm, physics_param=phys, _sync=False, _overflow_flag=flags[m])
@@ -282,7 +287,7 @@ def dynamics_mixed(batches, device, one_stream_each=None):
         done.record(st)
         cur.wait_event(done)
         res["state_seqs"].record_stream(cur)
-        out.append(res)
+        out[m] = res
     seen = flags.tolist()                                                              # the one wait of the call
     for (batch, (seen_nR, _)) in zip(batches, seen):
         if seen_nR > int(batch[4].task_config["max_nR"]):

@@ -192,11 +192,14 @@ def mixed(total, steps, reps, report=True):
     dt_seq_cpu = timed(lambda: [ag.dynamics_masked(b_[0], b_[1], b_[2], b_[3], dev, b_[4]) for b_ in batches], reps)
     dt_pin = timed(lambda: ag.dynamics_mixed(batches, dev, one_stream_each=True), reps)
     dt_fork = timed(lambda: ag.dynamics_mixed(batches, dev, one_stream_each=False), reps)
+    dt_given = timed(lambda: ag.dynamics_mixed(batches, dev, largest_first=False), reps)
+    dt_two = timed(lambda: ag.dynamics_mixed(batches, dev, streams_each=2), reps)
     dt = timed(fn_mixed, reps)
     out = {"config": f"mixed rope+granular+cloth, {total} variable-size graphs x {steps} steps", "ms_per_call": dt * 1e3,
            "rollout_steps_per_s": n_steps / dt, "entry": "adaptigraph_amd.dynamics_mixed (three materials dealt to three streams, one read-back)",
            "ms_three_sequential_dynamics_masked_calls": dt_seq * 1e3, "ms_three_sequential_calls_cpu_resident_pushes": dt_seq_cpu * 1e3,
            "ms_dynamics_mixed_engines_on_one_stream_each": dt_pin * 1e3, "ms_dynamics_mixed_engines_fork_by_size": dt_fork * 1e3,
+           "ms_dynamics_mixed_in_the_given_order_rope_granular_cloth": dt_given * 1e3, "ms_dynamics_mixed_two_streams_per_engine": dt_two * 1e3,
            "bit_equal_to_the_sequential_calls": bool(same)}
     if report:
         out.update(kernel_report(engines, fn, enc_fwd, node_fwd, dt * 1e3, edge_fwd))
