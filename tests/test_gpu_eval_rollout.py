@@ -34,8 +34,12 @@ def _dense(r, s, N, rows, dev):
     return Rr.to(dev), Rs.to(dev)
 
 
-def _setup(ag, dev):
-    g = load_golden("eval_rollout_softbody")
+FIXTURES = [("eval_rollout_softbody", {"fits", "knn", "topk"}),      # softbody.yaml as shipped
+            ("eval_rollout_surface", {"fits", "topk"})]               # surface-plane rule on (ratio 0.8), no rest frame, kNN range [1, 1]
+
+
+def _setup(ag, dev, name="eval_rollout_softbody"):
+    g = load_golden(name)
     meta = json.loads(bytes(g["meta_json"]).decode())
     mc, mat, ds = _cfg("softbody", int(g["pstep"]))
     m = ag.DynamicsPredictor(mc, mat, dict(ds, n_his=5), dev)
@@ -56,10 +60,11 @@ def _setup(ag, dev):
     return g, meta, m, graph, kw
 
 
-def test_backoff_rebuild_on_the_references_predictions_is_bit_exact(ag, dev):
+@pytest.mark.parametrize("name,kinds_want", FIXTURES)
+def test_backoff_rebuild_on_the_references_predictions_is_bit_exact(ag, dev, name, kinds_want):
     """Teacher-forced: the cloud the reference's builder was fed at every step -> the same bounds, the same back-off trail
     (kNN 0.7 -> 0.4 in steps of 0.1, then top-k 10 -> 9) and the same final edge list, bit for bit."""
-    g, meta, m, graph, kw = _setup(ag, dev)
+    g, meta, m, graph, kw = _setup(ag, dev, name)
     edges = split_edges(g, "step::")
     kinds = set()
     for i in range(g["pred_pos"].shape[0]):
@@ -77,15 +82,17 @@ def test_backoff_rebuild_on_the_references_predictions_is_bit_exact(ag, dev):
         n = int(el.n_edges[0])
         assert np.array_equal(el.recv[0, :n].cpu().numpy(), edges[i][0]) and np.array_equal(el.send[0, :n].cpu().numpy(), edges[i][1]), i
         kinds.add("fits" if len(tr) == 1 else "topk" if tr[-1][1] < meta["topk"] else "knn")
-    assert kinds == {"fits", "knn", "topk"}
+    assert kinds == kinds_want
 
 
+@pytest.mark.parametrize("name", [f[0] for f in FIXTURES])
 @pytest.mark.parametrize("dense", [True, False])
-def test_free_running_eval_rollout_stays_on_the_references_states(ag, dev, dense):
+def test_free_running_eval_rollout_stays_on_the_references_states(ag, dev, dense, name):
     """12 steps free-running through rollout_eval_step (dense=True: the graph dictionary carries one-hot Rr / Rs padded to max_nR like
     the reference's, and `truncate_graph` + `model(**graph)` work on it; dense=False: index lists): predictions within 1e-5 of the
-    reference's at every step, the rebuilt graphs identical to its (back-off steps included), the rest frame kept in slot 0."""
-    g, meta, m, graph, kw = _setup(ag, dev)
+    reference's at every step, the rebuilt graphs identical to its (back-off steps included), the rest frame kept in slot 0 (or, without
+    store_rest_state, the history shifted by one)."""
+    g, meta, m, graph, kw = _setup(ag, dev, name)
     edges = split_edges(g, "step::")
     worst = 0.0
     for i in range(g["pred_pos"].shape[0]):
@@ -104,10 +111,11 @@ def test_free_running_eval_rollout_stays_on_the_references_states(ag, dev, dense
             el = graph["edges"]
         n = int(el.n_edges[0])
         assert np.array_equal(el.recv[0, :n].cpu().numpy(), edges[i][0]) and np.array_equal(el.send[0, :n].cpu().numpy(), edges[i][1]), i
-        assert torch.equal(graph["state"][0, 0].cpu(), torch.from_numpy(g["hist0"][0]))      # store_rest_state (rollout.py:224-229)
+        if meta["store_rest_state"]:
+            assert torch.equal(graph["state"][0, 0].cpu(), torch.from_numpy(g["hist0"][0]))  # rollout.py:224-229
         assert torch.equal(graph["state"][0, -1, :g["pred_pos"].shape[1]], pred[0])
         assert np.array_equal(graph["action"][0, meta["max_nobj"]:].cpu().numpy(), g["eef_end"][i] - g["eef_start"][i])
-    print(f"eval rollout ({'dense Rr/Rs' if dense else 'index lists'}): max-abs position error over 12 free-running steps {worst:.2e}")
+    print(f"{name} ({'dense Rr/Rs' if dense else 'index lists'}): max-abs position error over {g['pred_pos'].shape[0]} free-running steps {worst:.2e}")
 
 
 def test_without_store_rest_state_the_history_shifts_by_one(ag, dev):

@@ -193,9 +193,9 @@ def test_forward_softbody_variant_nhis5_pstep4():
     assert np.abs(mot - g["pred_motion"]).max() < POS_TOL
 
 
-def _eval_rollout_fixture():
+def _eval_rollout_fixture(name="eval_rollout_softbody"):
     import json
-    g = load_golden("eval_rollout_softbody")
+    g = load_golden(name)
     meta = json.loads(bytes(g["meta_json"]).decode())
     (r0, s0), = split_edges(g, "first::")
     graph = {"state": g["hist0"], "action": g["action0"], "attrs": g["attrs"], "edges": (r0, s0), "p_instance": g["p_instance"],
@@ -203,12 +203,13 @@ def _eval_rollout_fixture():
     return g, meta, graph
 
 
-def test_eval_open_loop_rollout_vs_reference():
+@pytest.mark.parametrize("name,kinds_want", [("eval_rollout_softbody", {"fits", "knn", "topk"}), ("eval_rollout_surface", {"fits", "topk"})])
+def test_eval_open_loop_rollout_vs_reference(name, kinds_want):
     """rollout.py:108-260 (softbody.yaml: n_his 5, pstep 4, store_rest_state, tool-to-non-fixed rule with kNN back-off) driven
     step by step: per step the oracle, fed the reference's own graph, reproduces the prediction (tolerance), and - fed the
     reference's prediction - the bounds, the back-off trail and the final edge list (bit-exact); free-running it stays on the
     reference's states over all 12 steps, including the steps whose graph came out of the kNN and the top-k back-off."""
-    g, meta, graph = _eval_rollout_fixture()
+    g, meta, graph = _eval_rollout_fixture(name)
     W, S = O.weights_from_npz(g), g["pred_pos"].shape[0]
     edges = split_edges(g, "step::")
     kinds = set()
@@ -227,14 +228,17 @@ def test_eval_open_loop_rollout_vs_reference():
         assert np.array_equal(r, edges[i][0]) and np.array_equal(s, edges[i][1]), i
         kinds.add("fits" if len(tr) == 1 else "topk" if tr[-1][1] < meta["topk"] else "knn")
         assert np.array_equal(np.concatenate([g["pred_pos"][i], g["eef_start"][i]], 0), g["builder_states"][i])
-        # the reference's next graph (store_rest_state: frame 0 stays, rollout.py:224-229)
-        hist = np.concatenate([graph["state"][:1], graph["state"][2:], g["builder_states"][i][None]], 0)
+        # the reference's next graph (store_rest_state: frame 0 stays, rollout.py:224-229; else a plain shift, :231-232)
+        if meta["store_rest_state"]:
+            hist = np.concatenate([graph["state"][:1], graph["state"][2:], g["builder_states"][i][None]], 0)
+        else:
+            hist = np.concatenate([graph["state"][1:], g["builder_states"][i][None]], 0)
         delta = np.zeros_like(g["builder_states"][i]); delta[meta["max_nobj"]:] = g["eef_end"][i] - g["eef_start"][i]
         graph = dict(graph, state=hist, action=delta, edges=edges[i])
-        assert np.array_equal(graph["state"][0], g["hist0"][0])
+        assert np.array_equal(graph["state"][0], g["hist0"][0]) == bool(meta["store_rest_state"] or i < 0)
         # (b) free-running
         free, fpred, _ = O.eval_rollout_step(W, 4, free, g["eef_start"][i], g["eef_end"][i], meta)
         worst = max(worst, float(np.abs(fpred - g["pred_pos"][i]).max()))
         assert np.array_equal(free["edges"][0], edges[i][0]) and np.array_equal(free["edges"][1], edges[i][1]), i
-    assert kinds == {"fits", "knn", "topk"}
+    assert kinds == kinds_want
     assert worst < 1e-5, worst
