@@ -44,9 +44,9 @@ from .costs import running_cost
 from .physics_param_optimizer import dynamics_error, dynamics_error_sweep
 from .mppi import angle_normalize, clip_actions, sample_action_seq, optimize_action_mppi, mpc_iteration
 from .planner import Planner
-from .rollout import rollout_eval_step, surface_bounds
+from .rollout import rollout_eval, rollout_eval_step, surface_bounds
 
 __all__ = ["hw_queues", "Engine", "default_engine", "dynamics", "dynamics_masked", "dynamics_mixed", "rollout_work", "EdgeList", "construct_edges_from_states_batch", "construct_edges_from_states",
            "construct_edges_index", "construct_edges_with_backoff", "pad_torch", "truncate_graph", "DynamicsPredictor", "decode_action", "chamfer",
            "mean_chamfer", "box_loss", "rope_penalty", "cloth_penalty", "granular_penalty", "running_cost", "dynamics_error", "dynamics_error_sweep", "angle_normalize",
-           "clip_actions", "sample_action_seq", "optimize_action_mppi", "mpc_iteration", "Planner", "rollout_eval_step", "surface_bounds"]
+           "clip_actions", "sample_action_seq", "optimize_action_mppi", "mpc_iteration", "Planner", "rollout_eval", "rollout_eval_step", "surface_bounds"]

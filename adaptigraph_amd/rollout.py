@@ -89,3 +89,17 @@ def rollout_eval_step(model, graph, eef_kp_start, eef_kp_end, *, adj_thresh, top
         if k.endswith("_physics_param"):                                                  # :249-253
             new_graph[k] = graph[k]
     return new_graph, pred_state, pred_motion
+
+
+@torch.no_grad()
+def rollout_eval(model, graph, eef_pos, start_frame, n_steps, **cfg):
+    """n_steps of rollout_eval_step along a tool trajectory eef_pos (T, M, 3): step i uses the frame pair (start_frame + i - 1,
+    start_frame + i) the way rollout.py:158-161 looks it up from the next pair (n_future = 1).  -> (final graph, [pred_state (N,3)
+    per step], [back-off trail per step]).  The predictions stay on the device; nothing but the step's own decisions is read back."""
+    preds, trails = [], []
+    for i in range(1, n_steps + 1):
+        tr = []
+        graph, pred, _ = rollout_eval_step(model, graph, eef_pos[start_frame + i - 1], eef_pos[start_frame + i], trail=tr, **cfg)
+        preds.append(pred[0])
+        trails.append(tr)
+    return graph, preds, trails

@@ -120,3 +120,22 @@ def test_header_is_plain_c99_and_the_c_client_compiles_against_it(tmp_path):
                             os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", "-fsyntax-only",
                             os.path.join(ROOT, "tools", "abi_client", "abi_client.c")], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_hw_queues_record_and_late_import_warning(monkeypatch):
+    """adaptigraph_amd.hw_queues says who set GPU_MAX_HW_QUEUES and whether it can still take effect; a process that initialised HIP
+    before the import gets a RuntimeWarning instead of silence."""
+    import importlib
+    import warnings
+    import torch
+    import adaptigraph_amd as ag
+    assert ag.hw_queues["GPU_MAX_HW_QUEUES"] == __import__("os").environ["GPU_MAX_HW_QUEUES"]
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        info = ag._hw_queues_default()
+    assert info == {"GPU_MAX_HW_QUEUES": "8", "set_by": "adaptigraph_amd", "in_effect": False}
+    assert len(w) == 1 and "before the package was imported" in str(w[0].message)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")
+    assert ag._hw_queues_default() == {"GPU_MAX_HW_QUEUES": "6", "set_by": "environment", "in_effect": None}

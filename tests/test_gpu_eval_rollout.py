@@ -124,3 +124,24 @@ def test_without_store_rest_state_the_history_shifts_by_one(ag, dev):
     nxt, pred, _ = ag.rollout_eval_step(m, graph, g["eef_start"][0], g["eef_end"][0], dense=False, **dict(kw, store_rest_state=False))
     assert torch.equal(nxt["state"][0, :-1], before[0, 1:])                                  # rollout.py:231-232
     assert torch.equal(nxt["state"][0, -1, :pred.shape[1]], pred[0])
+
+
+def test_multi_step_driver_equals_the_steps(ag, dev):
+    """rollout_eval = the step function along the tool trajectory (frame pairs as rollout.py:158-161 looks them up): same predictions
+    and trails as stepping by hand, bit for bit; prints the time per step beside the reference's (this container, 8 threads)."""
+    import time
+    g, meta, m, graph, kw = _setup(ag, dev)
+    S, n_his = g["pred_pos"].shape[0], int(g["n_his"])
+    by_hand, gr = [], dict(graph)
+    for i in range(S):
+        gr, pred, _ = ag.rollout_eval_step(m, gr, g["eef_start"][i], g["eef_end"][i], dense=False, **kw)
+        by_hand.append(pred[0].clone())
+    assert np.array_equal(g["eef_pos"][n_his], g["eef_start"][0]) and np.array_equal(g["eef_pos"][n_his + 1], g["eef_end"][0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, preds, trails = ag.rollout_eval(m, graph, torch.from_numpy(g["eef_pos"]), n_his, S, dense=False, **kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / S
+    assert all(torch.equal(a, b) for a, b in zip(preds, by_hand))
+    assert [[list(x) for x in t] for t in trails] == meta["trails"]
+    print(f"eval open-loop step (230 + 5 particles, back-off included): {dt * 1e3:.2f} ms per step on the engine")
