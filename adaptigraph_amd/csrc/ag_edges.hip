@@ -719,7 +719,7 @@ __global__ __launch_bounds__(EW) void k_edge_emit(EdgeDev a) {
 // "goes through the relation encoder" bit per slot in LDS (a wave ballot: 64 consecutive slots = one 64-bit word, no atomics);
 // pass 2 gives every thread a contiguous run of those words: popcount, one block scan, and the set bits leave in slot order.
 // Same outputs bit for bit (recv per slot, ns list in slot order, pk, n_ns, n_edges, the share counters).
-constexpr int ELL_BITMAP_MAX_WORDS64 = 7168;               // 56 KB of dynamic LDS: 458,752 slots (N = 4096 rows of 112 slots)
+constexpr int ELL_BITMAP_MAX_WORDS64 = 16384;              // 128 KB of dynamic LDS: 1,048,576 slots (N = 4096 rows of up to 256 slots; the builder's limit is topk <= 128, M <= 8)
 __global__ __launch_bounds__(EW) void k_ell_index(EdgeDev a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(smem);
@@ -868,6 +868,9 @@ hipError_t launch_edge_build(const EdgeArgs& h, hipStream_t st, void (*mark)(voi
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_emit), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024 - 256);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ell_index), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 256);
         if (e != hipSuccess) return e;
         if (dev_id < 64) attr_devices |= 1ull << dev_id;

@@ -362,9 +362,14 @@ class Planner(object):
         back a placeholder.  merge_res all-gathers the winners.  Nothing is raised here (a rank that left the loop alone would
         leave the others hanging in merge_res's collective): errors are kept for merge_res."""
         if k == 0:
-            # the ranks evaluate different calls, so the callables must not issue collectives of their own
-            _require_rank_local(self.evaluate_traj, "evaluate_traj_fn")
-            _require_rank_local(self.model_rollout, "model_rollout_fn")
+            # the ranks evaluate different calls, so the callables must not issue collectives of their own (same config on every
+            # rank: every rank raises here, before any of them has entered anything)
+            try:
+                _require_rank_local(self.evaluate_traj, "evaluate_traj_fn")
+                _require_rank_local(self.model_rollout, "model_rollout_fn")
+            except ValueError:
+                self._series_i = 0
+                raise
         owner = k % world
         if k >= self.total_chunks and self._series_err is None:
             self._series_err = RuntimeError(f"call {k + 1} of a chunk loop announced with planner.total_chunks = {self.total_chunks}: "

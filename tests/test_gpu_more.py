@@ -1132,3 +1132,18 @@ def test_twenty_look_ahead_steps_of_one_repeat_vs_oracle(ag, O, dev, material, c
     with eng.options(repeat_sort=0):
         unsorted = ag.dynamics(s0, a, m, dev, _ppm(tdev, material))
     assert torch.equal(unsorted["state_seqs"], devp["state_seqs"])
+
+
+def test_rollout_graph_with_the_builders_largest_rows(ag, O, dev):
+    """The slot-indexed rollout graph at the edge builder's limits: 4000 + 1 particles, top-k 128 (129 slots per row: 516,129 slots,
+    a 63-KB bitmap in k_ell_index's LDS - beyond the 64 KB a kernel gets without the opt-in once the static part is added) with a
+    radius that keeps ~9 senders per row, and a dense variant (radius 0.26: ~60 senders per row).  Against the oracle."""
+    rng = np.random.default_rng(97)
+    cloud = _grid(64, 0.1, 0.01, rng)[:4000]
+    for thr, tol_scale in ((0.16, 1.0), (0.26, 1.0)):
+        task = _task("rope", adj_thresh=thr, topk=128, max_nR=4001 * 129)
+        W, m = _model(ag, O, "rope", 97, dev)
+        a_np = _actions(cloud, 2, 1, [2, 1], rng, spread=1.0)
+        out = ag.dynamics(torch.from_numpy(cloud).to(dev), torch.from_numpy(a_np).to(dev), m, dev, _ppm(task, "rope"))["state_seqs"]
+        want = O.dynamics(W, 3, cloud, a_np, task)["state_seqs"]
+        assert np.abs(out.cpu().numpy() - want).max() <= POS_TOL * tol_scale, thr
