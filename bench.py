@@ -372,13 +372,18 @@ def main():
     if args.plumbing_only:
         return plumbing_only(args, world, rank, local_rank)
     n_dev = torch.cuda.device_count()                       # (counting devices does not initialise HIP)
-    if os.environ.get("AG_BENCH_SHARE_GPU") != "1" and local_rank >= n_dev:
-        sys.exit(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) has no GPU of its own: {n_dev} device(s) visible, {world} ranks "
-                 "(one process per GPU; AG_BENCH_SHARE_GPU=1 is the one-GPU rehearsal mode)")
+    if n_dev == 0:
+        sys.exit(f"bench.py: rank {rank} sees no GPU")
     # Rehearsal hooks (never set by the driver): AG_BENCH_SHARE_GPU=1 maps every rank onto the GPUs that exist (two
     # ranks on a one-GPU box) and AG_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device.
-    if os.environ.get("AG_BENCH_SHARE_GPU") == "1":
-        local_rank %= torch.cuda.device_count()
+    if local_rank >= n_dev:
+        # Either a launcher that isolates the GPUs per rank (every rank sees only its own device, as index 0) or fewer GPUs than
+        # ranks.  Take the device that exists; with the nccl backend RCCL itself refuses two ranks on one physical device, loudly,
+        # and multi_gpu.distinct_devices in the line says how many physical devices the ranks really ran on.
+        if os.environ.get("AG_BENCH_SHARE_GPU") != "1":
+            print(f"bench.py: rank {rank}: LOCAL_RANK {local_rank} but {n_dev} visible device(s): using device {local_rank % n_dev}",
+                  file=sys.stderr, flush=True)
+        local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # AG_BENCH_FORCE_DIST=1 (never set by the driver): also a ONE-rank run initialises the process group and takes the
