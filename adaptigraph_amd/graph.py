@@ -132,7 +132,7 @@ def _plane_side(name, pos, max_y, max_x, max_z, min_x, min_z):
 def _apply_tool_rule(eng, dev, el, pos, mask_u8, tool_u8, n_tools, subset, kNN):
     """ag_edges_apply_tool_rule on a single-graph EdgeList -> new EdgeList."""
     N = el.N
-    edge_cap = max(1, int(el.n_edges[0].item()) + N * n_tools)              # every rule adds at most N*M tool edges
+    edge_cap = max(1, min(el.edge_cap, N * N) + N * n_tools)                # every rule adds at most N*M tool edges (no read-back)
     recv = torch.empty((1, edge_cap), device=dev, dtype=torch.int32)
     send = torch.empty((1, edge_cap), device=dev, dtype=torch.int32)
     row_ptr = torch.empty((1, N + 1), device=dev, dtype=torch.int32)
@@ -141,16 +141,14 @@ def _apply_tool_rule(eng, dev, el, pos, mask_u8, tool_u8, n_tools, subset, kNN):
     eng.check(eng.lib.ag_edges_apply_tool_rule(eng.ctx, current_stream(dev), ptr(pos), ptr(mask_u8), ptr(tool_u8), N, n_tools,
                                                ptr(el.send), ptr(el.row_ptr), ptr(sub_u8), float(kNN), edge_cap, ptr(recv),
                                                ptr(send), ptr(row_ptr), ptr(n_edges)))
-    if int(n_edges[0].item()) < 0:
-        raise RuntimeError("internal: tool count passed to ag_edges_apply_tool_rule does not match tool_mask")
-    return EdgeList(recv, send, row_ptr, n_edges, N)
+    return EdgeList(recv, send, row_ptr, n_edges, N)        # (n_edges < 0 = tool count mismatch: checked where n_edges is next read)
 
 
 def _tool_sender_edges(el, tool_b):
     """adj[obj_tool_mask_2].sum() (graph.py:128-129, :178-179): edges whose sender is a tool particle.  (Receivers of
     edges are valid particles by construction, which is the other half of obj_tool_mask_2.)"""
-    n = int(el.n_edges[0].item())
-    return int(tool_b[el.send[0, :n].long()].sum().item())
+    live = torch.arange(el.edge_cap, device=el.send.device) < el.n_edges[0]          # one read-back instead of two
+    return int((tool_b[el.send[0].clamp(0, el.N - 1).long()] & live).sum().item())
 
 
 def construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=10, connect_tools_all=False, max_y=None,
@@ -216,6 +214,8 @@ def construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=10, co
 
     if as_index:
         return el
+    if int(el.n_edges[0].item()) < 0:
+        raise RuntimeError("internal: tool count passed to ag_edges_apply_tool_rule does not match tool_mask")
     Rr, Rs = el.to_dense()
     return Rr[0], Rs[0]
 
@@ -234,6 +234,8 @@ def construct_edges_with_backoff(states, adj_thresh, mask, tool_mask, topk, max_
     while True:
         el = construct_edges_from_states(states, adj_thresh, mask, tool_mask, topk=k_now, kNN=kNN, as_index=True, **rules)
         n_rel = int(el.n_edges[0].item())
+        if n_rel < 0:
+            raise RuntimeError("internal: tool count passed to ag_edges_apply_tool_rule does not match tool_mask")
         if trail is not None:
             trail.append((float(kNN), int(k_now), n_rel))
         if n_rel <= max_nR:                                                             # rollout.py:192-194 pad_torch fits
