@@ -287,12 +287,13 @@ def _loop_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_the_references_chunk_loop_is_dealt_to_the_ranks_and_merges_to_the_one_rank_result(world):
     """planner_config['group'] + `planner.total_chunks = n_chunk` (plan.py:210): call ci of the loop of plan.py:241-247 runs on
     rank ci % world, the others draw its samples and get a placeholder; merge_res all-gathers the winners and broadcasts the best
     one's outputs.  Bit-equal to the one-rank loop (and to the reference Planner's own recorded result), generators in step,
-    errors raised on every rank."""
+    errors raised on every rank.  world 8 (the node's size): fewer calls than ranks in every series here - ranks that own no call
+    still draw, still take part in the merge."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -357,7 +357,7 @@ def _mixed_worker(rank, world, port, q):
 
 def test_gloo_mixed_batch_values_and_rank0_bounds():
     ctx = mp.get_context("spawn")
-    for world in (2, 4):
+    for world in (2, 4, 8):
         q = ctx.Queue()
         port = _free_port()
         procs = [ctx.Process(target=_mixed_worker, args=(r, world, port, q)) for r in range(world)]
