@@ -75,3 +75,13 @@ def test_torchrun_wrapped_form_is_unchanged():
     line = _line(p.stdout)
     assert line["n_gpus"] == 2 and line["launched_by"] == "external launcher"
     assert "without a launcher" not in p.stderr
+
+
+def test_bare_command_with_eight_ranks():
+    """the node's size: `python bench.py --gpus 8` alone starts eight ranks that meet (gloo, no GPU: --plumbing-only)"""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--plumbing-only", "ok"], env=_env(), cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = _line(p.stdout)
+    assert line["n_gpus"] == 8 and [s["local_rank"] for s in line["plumbing"]] == list(range(8))
+    assert all(s["world_dist"] == 8 for s in line["plumbing"]) and len({s["pid"] for s in line["plumbing"]}) == 8
