@@ -696,6 +696,20 @@ def main():
             # HIP multiplexes streams onto this many hardware queues; the engine's four + RCCL's need more than the default 4
             "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "hw_queues": ag.hw_queues},
         }
+        # The reward vector of this batch is deterministic (no float atomics; sharded == unsharded bit for bit): a run of the default
+        # workload - on any number of GPUs - must reproduce the SHA-256 of the committed one-GPU evidence line, whose parity_check
+        # compared the same rollouts with the reference's own outputs.  This is the parity statement of an N > 1 line, which has
+        # no CPU leg of its own.
+        prof = os.path.join(ROOT, "profiles", latest("bench_default.json"))
+        if os.path.exists(prof):
+            pj = json.load(open(prof))
+            same_workload = all(pj["config"].get(k) == line["config"].get(k) for k in ("candidates", "horizon", "particles", "edges_per_graph",
+                                                                                        "action_path"))
+            if same_workload and "reward_sha256" in pj:
+                line["parity_vs_one_gpu_evidence"] = {"equal": pj["reward_sha256"] == line["reward_sha256"], "expected_sha256": pj["reward_sha256"],
+                                                      "source": f"profiles/{latest('bench_default.json')} (its parity_check.vs_reference: "
+                                                                f"{pj['parity_check']['vs_reference']['candidates_within_tol_all_steps']} of "
+                                                                f"{pj['parity_check']['vs_reference']['n_candidates']} candidates within 1e-5 of the reference)"}
         if multi is not None:
             line["multi_gpu"] = multi
         # whole-rollout arithmetic rate: FLOPs the kernels execute per rollout step and candidate
@@ -747,9 +761,12 @@ def main():
                             "through the LDS, not VALU issue): profiles/r05_bf16x3_limiter.json"}
         if not dist_on and not args.no_cpu_baseline:
             line["cpu_baseline"], line["parity_check"] = cpu_baseline(cloud, task, Wt, actions.numpy(), picks, timed_seqs, ref)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
         if "parity_check" in line and not line["parity_check"]["ok"]:
             sys.exit("bench: the timed rollout differs from the reference fixtures / the oracle by more than 1e-5")
+        if line.get("parity_vs_one_gpu_evidence", {}).get("equal") is False:
+            sys.exit("bench: the reward vector of the default batch differs from the committed one-GPU evidence run's (profiles/): "
+                     "sharded and unsharded evaluations must agree bit for bit")
     if dist_on:
         dist.destroy_process_group()
 

@@ -46,6 +46,7 @@ def test_bench_default_profile_is_a_bench_line():
                     first[f["candidate"]] = f
             assert all(f["reference_selection_margin"] < f["margin_within_reach_of_the_deviation_before"] for f in first.values())
             assert d["env"]["hw_queues"]["GPU_MAX_HW_QUEUES"] == d["env"]["GPU_MAX_HW_QUEUES"]
+    assert len(d["reward_sha256"]) == 64        # bench.py compares every default-workload line's reward SHA with this one (any N)
     # the names bench.py looks up must be the files that are committed
     src = open(os.path.join(ROOT, "bench.py")).read()
     for stem in ("traffic_k_edge_enc.json", "traffic_k_node_prop.json"):
