@@ -500,17 +500,19 @@ def main():
         for _ in range(20):
             dist.all_reduce(two, op=dist.ReduceOp.MAX); _agc(probe, B)
         sync_all()
+        # which physical device every rank ran on - as plain integers through the tensor collectives the timed path itself uses (no
+        # pickled objects: nothing in this diagnostic block may be the first thing to fail on a real multi-GPU run)
         props = torch.cuda.get_device_properties(dev)
-        ids = [None] * world
-        if world > 1:
-            dist.all_gather_object(ids, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": dev.index,
-                                         "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None,
-                                         "pid": os.getpid()})
-        else:
-            ids = [{"rank": 0, "local_rank": 0, "device_index": dev.index, "pci_bus_id": getattr(props, "pci_bus_id", None),
-                    "uuid": str(getattr(props, "uuid", "")) or None, "pid": os.getpid()}]
+        uuid = str(getattr(props, "uuid", "")) or ""
+        import zlib
+        mine = torch.tensor([rank, int(os.environ.get("LOCAL_RANK", "0")), dev.index if dev.index is not None else 0,
+                             int(getattr(props, "pci_bus_id", -1) or -1), zlib.crc32(uuid.encode()), os.getpid()], device=dev, dtype=torch.int64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ids = [dict(zip(("rank", "local_rank", "device_index", "pci_bus_id", "uuid_crc32", "pid"), [int(v) for v in t.tolist()])) for t in allr]
         multi = {"world_size": dist.get_world_size(), "launched_by": os.environ.get("AG_BENCH_LAUNCHED_BY", "external launcher"),
-                 "ranks": ids, "distinct_devices": len({(i["device_index"], i["uuid"], i["pci_bus_id"]) for i in ids}),
+                 "ranks": ids, "distinct_devices": len({(i["pci_bus_id"], i["uuid_crc32"]) if i["pci_bus_id"] >= 0 or i["uuid_crc32"] else
+                                                        ("index", i["device_index"]) for i in ids}),
                  "per_rank_ms_per_step": [float(t.item()) / args.steps * 1e3 for t in per_rank],
                  "exchange_us_per_step": (time.perf_counter() - tc) / 20 * 1e6,
                  "backend": dist.get_backend(), "candidates_per_rank": [shard_bounds(B, world, r)[1] - shard_bounds(B, world, r)[0] for r in range(world)]}
