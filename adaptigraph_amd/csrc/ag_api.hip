@@ -18,6 +18,7 @@ int edge_ell_stride(int N, int topk);
 size_t lat_weights_floats();
 size_t lat_weights_offset(int which);
 hipError_t launch_edge_enc_lat(const float* wl, const GraphBufs& g, hipStream_t st);
+hipError_t launch_node_enc_lat(const float* wl, const GraphBufs& g, long row0, long nrows, hipStream_t st);
 hipError_t launch_node_prop_lat(const float* wl, const GraphBufs& g, int round, bool last, float clamp, float* pred_pos,
                                 float* pred_motion, hipStream_t st);
 #ifdef AG_DIAG   // diagnostic build only (ag_diag.hip)
@@ -527,6 +528,13 @@ bool lat_edge_for(const ag_ctx* c, const GraphBufs& g) {
     const long edge_wgs = (long)g.B * g.c_cap / 128;
     return lat_available(c, g) && (c->opt.latency >= 0 ? c->opt.latency == 1 : edge_wgs <= 128);
 }
+// particle-encoder chain (class table: 2 N_o + B M rows per look-ahead step): the latency-mode kernel while its grid of 32-row
+// workgroups fits one round of the chip (two per CU); beyond that the 128-row throughput kernel
+hipError_t node_enc_for(const ag_ctx* c, const GraphBufs& g, long row0, long nrows, hipStream_t st) {
+    const long rows = g.cls_on ? nrows : (long)g.B * g.N;
+    const bool lat = lat_available(c, g) && (c->opt.latency >= 0 ? c->opt.latency == 1 : rows <= 512L * 32);
+    return lat ? launch_node_enc_lat(c->d_wlat, g, row0, nrows, st) : launch_node_enc(c->d_w, g, row0, nrows, st);
+}
 bool lat_node_for(const ag_ctx* c, const GraphBufs& g) {
     const long node_wgs = ((long)g.B * g.N + 127) / 128;
     return lat_available(c, g) && (c->opt.latency >= 0 ? c->opt.latency == 1 : node_wgs <= 64);
@@ -542,7 +550,7 @@ int run_edge_chain(ag_ctx* c, const GraphBufs& g, hipStream_t st) {
 // one model forward on a prepared workspace (node_in, feat12, group, edges all set).  With g.cls_on the particle
 // encoder outputs already sit in the class table (encoded at look-ahead-step start) and k_node_enc is skipped.
 int run_model(ag_ctx* c, const GraphBufs& g, float* pred_pos, float* pred_motion, hipStream_t st) {
-    if (!g.cls_on) { Scoped p(c, FAM_NODE_ENC); HIPCHK(c, launch_node_enc(c->d_w, g, 0, (long)g.B * g.N, st)); }
+    if (!g.cls_on) { Scoped p(c, FAM_NODE_ENC); HIPCHK(c, node_enc_for(c, g, 0, (long)g.B * g.N, st)); }
     const bool lat_node = lat_node_for(c, g);
     if (g.send_pk && lat_node) return fail(c, AG_ERR_INVALID, "internal: shared first forward on the latency-mode chains");
     int rc = run_edge_chain(c, g, st);
@@ -777,6 +785,10 @@ int ag_ctx_load_weights(ag_ctx* c, const float* const* t, int32_t n) {
         pack_layer_lat(L + lat_weights_offset(7), t[16], NF, 0, NF, NF, t[17], false);            // predictor 0
         pack_layer_lat(L + lat_weights_offset(8), t[18], NF, 0, NF, NF, t[19], false);            // predictor 1
         pack_layer_lat(L + lat_weights_offset(9), t[20], NF, 0, 3, NF, t[21], true);              // predictor 2 (3 outputs)
+        pack_first_lat(L + lat_weights_offset(10), t[0], IN_DIM, t[1], 1);                         // particle encoder 0 (r06)
+        pack_layer_lat(L + lat_weights_offset(11), t[2], NF, 0, NF, NF, t[3], false);             // particle encoder 2
+        pack_layer_lat(L + lat_weights_offset(12), t[4], NF, 0, NF, NF, t[5], false);             // particle encoder 4
+        pack_layer_lat(L + lat_weights_offset(13), t[12], 2 * NF, 0, NF, NF, t[13], false);       // Wa + b_pp
         if (!c->d_wlat) HIPCHK(c, dev_alloc(c, reinterpret_cast<void**>(&c->d_wlat), wl.size() * 4));
         HIPCHK(c, hipMemcpy(c->d_wlat, wl.data(), wl.size() * 4, hipMemcpyHostToDevice));
     }
@@ -1381,7 +1393,7 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             }
             w.r.ragged = 0; w.r.clamp = c->dims.motion_clamp;
             { Scoped sc(c, FAM_ROLL_INIT); HIPCHK(c, launch_roll_init(ra, w.r, g, st)); }
-            { Scoped sc(c, FAM_NODE_ENC); HIPCHK(c, launch_node_enc(c->d_w, g, 0, 2L * p->N_o + p->M, st)); }
+            { Scoped sc(c, FAM_NODE_ENC); HIPCHK(c, node_enc_for(c, g, 0, 2L * p->N_o + p->M, st)); }
             for (int ai = 1; ai <= R_base; ++ai) {
                 HIPCHK(c, launch_edge_build(ea, st, prof_mark, c));
                 if (g.ns_edge && !ell_full) { Scoped sc(c, FAM_EDGE_EMIT); HIPCHK(c, launch_edge_nonself(w.recv, w.send, w.row_ptr, 1, N, edge_cap, w.ns_edge, w.n_ns, nullptr, st)); }
@@ -1519,8 +1531,8 @@ int rollout_impl(ag_ctx* c, void* stream, const ag_rollout_params* p, const floa
             { Scoped s(c, FAM_ROLL_INIT); HIPCHK(c, launch_roll_init(ra, w.r, g, cs)); }
             { Scoped s(c, FAM_NODE_ENC);
               const long tool0 = 2L * p->N_o;
-              if (!obj_cls_ready[ci % ns]) HIPCHK(c, launch_node_enc(c->d_w, g, 0, tool0 + (long)nb * p->M, cs));
-              else HIPCHK(c, launch_node_enc(c->d_w, g, tool0, (long)nb * p->M, cs)); }
+              if (!obj_cls_ready[ci % ns]) HIPCHK(c, node_enc_for(c, g, 0, tool0 + (long)nb * p->M, cs));
+              else HIPCHK(c, node_enc_for(c, g, tool0, (long)nb * p->M, cs)); }
             obj_cls_ready[ci % ns] = true;
             int n_live = nb;
             c->steps_bound += max_rep;

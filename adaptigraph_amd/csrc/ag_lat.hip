@@ -168,7 +168,11 @@ struct WLat {                              // offsets (floats) into the latency 
     static constexpr int P_P0 = N_W3 + LAYER_FLOATS;
     static constexpr int P_P1 = P_P0 + LAYER_FLOATS;
     static constexpr int P_P2 = P_P1 + LAYER_FLOATS;                          // head
-    static constexpr int TOTAL = P_P2 + HEAD_FLOATS;
+    static constexpr int N_L1 = P_P2 + HEAD_FLOATS;                           // r06, node encode chain: 1 chunk (2 k-steps: 6 inputs + bias)
+    static constexpr int N_L2 = N_L1 + CHUNK_FLOATS;
+    static constexpr int N_L3 = N_L2 + LAYER_FLOATS;
+    static constexpr int N_WA = N_L3 + LAYER_FLOATS;                          // Wa + b_pp
+    static constexpr int TOTAL = N_WA + LAYER_FLOATS;
 };
 
 // rel_inputs (17) -> Encoder(17,150,150) -> W1*enc + b_rp  => C      (model.py:249-282, 303, 317-318 first block)
@@ -228,6 +232,67 @@ __global__ __launch_bounds__(WGL, 2) void k_edge_enc_lat(EDev g) {
     put_tiles(y, imgB, par, j, lg);
     __syncthreads();
     store_image(img + IMG_FLOATS, g.C, rows, tid);
+}
+
+// ------------------------------------------------------------------------------------------------ node encode chain (r06)
+// p_inputs (6) -> Encoder(6,150,150) = p_enc => eff;  P = Wa*p_enc + b_pp;  U = W2*p_enc;  V = W3*p_enc   (model.py:297-298, 317-318,
+// 328-330) - ag_mlp.hip: k_node_enc with 32-row workgroups whose four wavefronts split every layer.  The class table of a rollout
+// (2 N_o + B M rows, once per look-ahead step) is a handful of 128-row workgroups there: six layers of ~10 us each, 66 us whatever
+// the batch; here 29.  Same k order per layer, same bits (test_latency_kernels_equal_throughput_kernels_bitwise).
+struct NEDev { const float* w; const float* node_in; float* eff; float* P; float* U; float* V; long row0, nrows; };
+
+__global__ __launch_bounds__(WGL, 2) void k_node_enc_lat(NEDev g) {
+    __shared__ __attribute__((aligned(16))) float img[2 * IMG_FLOATS];
+    __shared__ int rows[ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rg = wave >> 1, par = wave & 1, j = lane & 15, lg = lane >> 4;
+    const long rend = g.row0 + g.nrows;
+    const long row = g.row0 + (long)blockIdx.x * ROWS + 16 * rg + j;
+    const bool valid = row < rend;
+    const long rowc = valid ? row : rend - 1;
+    if (par == 0 && lg == 0) rows[16 * rg + j] = valid ? (int)row : -1;
+    float bs[2];                                             // B operand of the 2 first-layer k-steps: feature 4s + g
+    {
+        const float* p = g.node_in + rowc * NODE_IN;         // [attr_obj, attr_tool, phys, act_xyz, 1, 0]
+        bs[0] = p[lg];
+        bs[1] = p[4 + lg];
+    }
+    float* imgA = img + rg * 16 * IMG_PITCH;
+    float* imgB = imgA + IMG_FLOATS;
+    Act x; Out y;
+    zero(y);
+    layer_first<2>(g.w + WLat::N_L1, bs, y, par, lane);
+    relu_one(y, par, lg);
+    put_tiles(y, imgA, par, j, lg);
+    __syncthreads();
+    get_act(x, imgA, j, lg);
+    zero(y);
+    layer(g.w + WLat::N_L2, x, y, par, lane);
+    relu_one(y, par, lg);
+    put_tiles(y, imgB, par, j, lg);
+    __syncthreads();
+    get_act(x, imgB, j, lg);
+    zero(y);
+    layer(g.w + WLat::N_L3, x, y, par, lane);
+    relu_one(y, par, lg);                                    // p_enc (slot 150 = 1 for the bias of Wa)
+    put_tiles(y, imgA, par, j, lg);
+    __syncthreads();
+    store_image(img, g.eff, rows, tid);
+    get_act(x, imgA, j, lg);
+    zero(y);
+    layer(g.w + WLat::N_WA, x, y, par, lane);
+    put_tiles(y, imgB, par, j, lg);
+    __syncthreads();                                         // (also: everybody has read image 0 - it may be rewritten)
+    store_image(img + IMG_FLOATS, g.P, rows, tid);
+    zero(y);
+    layer(g.w + WLat::N_W2, x, y, par, lane);
+    put_tiles(y, imgA, par, j, lg);
+    __syncthreads();                                         // (also: the P rows have left image 1)
+    store_image(img, g.U, rows, tid);
+    zero(y);
+    layer(g.w + WLat::N_W3, x, y, par, lane);
+    put_tiles(y, imgB, par, j, lg);
+    __syncthreads();
+    store_image(img + IMG_FLOATS, g.V, rows, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ propagate chain
@@ -441,10 +506,20 @@ __global__ __launch_bounds__(WGL, 2) void k_node_prop_lat(NDev g) {
 }  // namespace lat
 
 size_t lat_weights_floats() { return lat::WLat::TOTAL; }
-size_t lat_weights_offset(int which) {   // 0 E_L1, 1 E_L2, 2 E_L3, 3 E_W1, 4 P_WB, 5 N_W2, 6 N_W3, 7 P_P0, 8 P_P1, 9 P_P2
+size_t lat_weights_offset(int which) {   // 0 E_L1, 1 E_L2, 2 E_L3, 3 E_W1, 4 P_WB, 5 N_W2, 6 N_W3, 7 P_P0, 8 P_P1, 9 P_P2, 10 N_L1, 11 N_L2, 12 N_L3, 13 N_WA
     using W = lat::WLat;
-    const int o[10] = {W::E_L1, W::E_L2, W::E_L3, W::E_W1, W::P_WB, W::N_W2, W::N_W3, W::P_P0, W::P_P1, W::P_P2};
+    const int o[14] = {W::E_L1, W::E_L2, W::E_L3, W::E_W1, W::P_WB, W::N_W2, W::N_W3, W::P_P0, W::P_P1, W::P_P2, W::N_L1, W::N_L2, W::N_L3, W::N_WA};
     return o[which];
+}
+hipError_t launch_node_enc_lat(const float* wl, const GraphBufs& g, long row0, long nrows, hipStream_t st) {
+    lat::NEDev d{wl, g.node_in, g.eff, g.P, g.UV[1][0], g.UV[1][1], 0, (long)g.B * g.N};   // (what to_dev gives k_node_enc)
+    if (g.cls_on) {   // encode a slice of the class table instead of all B*N rows
+        d.node_in = g.c_node_in; d.eff = g.c_eff; d.P = g.c_P; d.U = g.c_U; d.V = g.c_V;
+        d.row0 = row0; d.nrows = nrows;
+    }
+    if (d.nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lat::k_node_enc_lat, dim3((unsigned)((d.nrows + lat::ROWS - 1) / lat::ROWS)), dim3(lat::WGL), 0, st, d);
+    return hipGetLastError();
 }
 hipError_t launch_edge_enc_lat(const float* wl, const GraphBufs& g, hipStream_t st) {
     lat::EDev d{wl, g.node_in, g.feat12, g.group, g.C, g.recv, g.send, g.n_edges, g.ns_edge, g.n_ns,
