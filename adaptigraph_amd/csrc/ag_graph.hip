@@ -81,15 +81,17 @@ constexpr int RT = 1024;
 __device__ float tool_y(const float* src, const uint8_t* om, int N_o, int y_mode, float* red, int* redi) {
     const int tid = threadIdx.x;
     if (y_mode == 0) {
+        // (a minimum does not depend on the order it is taken in: wave shuffles, then one value per wavefront - two barriers
+        // instead of the ten of a tree over 1024 LDS slots; r06)
         float m = 3.4e38f;
         for (int i = tid; i < N_o; i += RT) m = fminf(m, src[3 * i + 1]);
-        red[tid] = m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) red[tid >> 6] = m;
         __syncthreads();
-        for (int o = RT / 2; o > 0; o >>= 1) {
-            if (tid < o) red[tid] = fminf(red[tid], red[tid + o]);
-            __syncthreads();
-        }
-        const float y = red[0];
+        float y = red[0];
+#pragma unroll
+        for (int w = 1; w < RT / 64; ++w) y = fminf(y, red[w]);
         __syncthreads();
         return y;
     }
