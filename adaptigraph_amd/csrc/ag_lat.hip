@@ -88,18 +88,22 @@ __device__ __forceinline__ void get_tiles(Out& o, const float* img_rg, int par, 
 
 // one 160-wide layer for this wave's five tiles: out (+)= W[tiles] * x.  Weight fragments come straight from global memory
 // (L2-resident, 1 KB per wave-instruction), three chunks ahead of their use.
+#ifndef AG_LAT_PF
+#define AG_LAT_PF 2                          // chunks of weight fragments in flight ahead of the one being multiplied
+#endif
 __device__ __forceinline__ void layer(const float* __restrict__ w, const Act& x, Out& out, int par, int lane) {
     const float* wp = w + (par * 64 + lane) * 4;                     // tile par of chunk 0; tiles step by 2 * 256 floats
-    f32x4 a[3][5];
+    constexpr int PF = AG_LAT_PF, RING = PF + 1;
+    f32x4 a[RING][5];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < PF; ++c)
 #pragma unroll
         for (int m = 0; m < 5; ++m) a[c][m] = *reinterpret_cast<const f32x4*>(wp + c * CHUNK_FLOATS + m * 512);
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
-        if (c + 2 < NCHUNK) {
+        if (c + PF < NCHUNK) {
 #pragma unroll
-            for (int m = 0; m < 5; ++m) a[(c + 2) % 3][m] = *reinterpret_cast<const f32x4*>(wp + (c + 2) * CHUNK_FLOATS + m * 512);
+            for (int m = 0; m < 5; ++m) a[(c + PF) % RING][m] = *reinterpret_cast<const f32x4*>(wp + (c + PF) * CHUNK_FLOATS + m * 512);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -109,7 +113,7 @@ __device__ __forceinline__ void layer(const float* __restrict__ w, const Act& x,
                 const float b = x.t[T][r];
 #pragma unroll
                 for (int m = 0; m < 5; ++m)
-                    out.t[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c % 3][m][e], b, out.t[m], 0, 0, 0);
+                    out.t[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c % RING][m][e], b, out.t[m], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);                           // keep the prefetch distance: no hoisting of all 50 reads
